@@ -1,0 +1,146 @@
+/*
+ * sleekit_amd.h -- C ABI of the MI355X (gfx950) GPTQ/OBQ layer-quantization engine.
+ *
+ * Drop-in boundary for the hot path of Coloquinte/sleekit.  The reference is pure
+ * Python/NumPy and has no FFI of its own; each entry point below replaces one
+ * NumPy function (cited as file:line relative to the reference tree) and is what
+ * a ctypes binding in the reference would bind.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (hipMalloc / torch);
+ *     matrices are dense row-major; `R` = output rows of W, `n` = input columns;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work and never
+ *     synchronise, allocate or copy from host memory, so they can be captured
+ *     into a hipGraph;
+ *   - scratch comes from a caller-provided workspace of at least
+ *     slk_workspace_bytes(R, n) bytes, 256-byte aligned; one workspace may be
+ *     shared by consecutive calls on the same stream;
+ *   - return value: SLK_OK or a negative SLK_E_* code; slk_last_error() gives the
+ *     message of the last failure on the calling thread;
+ *   - a uniform codebook is (levels, lo, hi): `levels` evenly spaced values on
+ *     [lo, hi]; step and zero are formed in float32 exactly as the reference does.
+ */
+#ifndef SLEEKIT_AMD_H
+#define SLEEKIT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLK_OK 0
+#define SLK_E_ARG (-1)    /* invalid argument (shape, mode, null pointer)            */
+#define SLK_E_NOT_PD (-2) /* reported through `info`, see slk_chol_inverse_upper     */
+#define SLK_E_HIP (-3)    /* a HIP runtime call or kernel launch failed              */
+#define SLK_E_WS (-4)     /* workspace too small                                     */
+
+/* codebook maps, slk_codebook_apply `what` */
+#define SLK_CB_VALUE 0 /* float32 out */
+#define SLK_CB_INDEX 1 /* uint8 out (levels <= 256) */
+#define SLK_CB_UP 2    /* float32 out */
+#define SLK_CB_DOWN 3  /* float32 out */
+
+/* column orders, slk_hessian_prepare `order_mode` (obq.py:58-86) */
+#define SLK_ORDER_NONE 0
+#define SLK_ORDER_DIAG 1
+#define SLK_ORDER_ERR 2   /* needs `miss` = column sums of |q(W) - W|   */
+#define SLK_ORDER_SQERR 3 /* needs `miss` = column sums of (q(W) - W)^2 */
+
+typedef void *slk_stream_t;
+
+/* Library / device --------------------------------------------------------- */
+int slk_abi_version(void);
+const char *slk_last_error(void);
+/* Scratch bytes that any call below may use for an (R, n) layer. */
+size_t slk_workspace_bytes(int R, int n);
+
+/* a7  UniformCodebook.quantize_value/index/up/down  (sleekit/codebook.py:43-95)
+ *     out[i] = map(x[i]); float32 arithmetic, IEEE divide, round-half-even.    */
+int slk_codebook_apply(const float *x, size_t count, int levels, float lo, float hi, int what,
+                       void *out, slk_stream_t stream);
+
+/* a14 apply_scaling on axis 0  (sleekit/scaling.py:21-25, 73, 80)
+ *     invert == 0: out[r][j] = x[r][j] / scale[r]
+ *     invert == 1: out[r][j] = x[r][j] / (1.0f / scale[r])   (two IEEE divides)  */
+int slk_rows_divide(const float *x, const float *scale, int R, int n, int invert, float *out,
+                    slk_stream_t stream);
+
+/* a2  remove_input_bias  (sleekit/obq.py:14-25): out = H - mean mean^T (float32). */
+int slk_hessian_strip_mean(const float *H, const float *mean, int n, float *out,
+                           slk_stream_t stream);
+
+/* a2  remove_dead_values  (sleekit/obq.py:28-35), in place:
+ *     H[d][d] = mean(diag H) and W[:, d] = 0 for every d with H[d][d] == 0.
+ *     The mean follows NumPy's float32 pairwise order. `W` may be NULL (R = 0). */
+int slk_hessian_patch_dead(float *H, float *W, int R, int n, void *workspace, size_t ws_bytes,
+                           slk_stream_t stream);
+
+/* a1  Sleekit.add_batch, Linear branch  (sleekit/statistics.py:41-43, 76-87)
+ *     X: T tokens x n features, row-major.  With c = count_before, c' = c + T:
+ *     mean = mean * (c/c') + colsum(X) / c';   H = H * (c/c') + X^T X / c'.
+ *     float32 MFMA; matches the reference to float32 GEMM tolerance.           */
+int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T,
+                           long long count_before, slk_stream_t stream);
+
+/* a4  column statistics for the err / sqerr orders  (sleekit/obq.py:60-69)
+ *     miss[j] = sum over rows, in row order, of |q(W) - W| (squared == 0) or its square. */
+int slk_column_miss(const float *W, int R, int n, int levels, float lo, float hi, int squared,
+                    float *miss, slk_stream_t stream);
+
+/* a3+a4+a5  damping, ordering, permutation  (sleekit/obq.py:198-204)
+ *     Hd = float64(H) + float32(damp * mean(diag H)) * I
+ *     order = argsort(-diag(Hd) [* miss])            (stable on ties)
+ *     order_out[n] (int64) and the permuted, index-reversed damped Hessian that
+ *     slk_chol_inverse_upper consumes are written to the workspace-independent
+ *     outputs `order_out` and `A` (float64, ld = slk_factor_ld(n)).            */
+int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const float *miss,
+                        long long *order_out, double *A, void *workspace, size_t ws_bytes,
+                        slk_stream_t stream);
+/* Leading dimension (and row count) of the padded float64 matrices A / scratch. */
+int slk_factor_ld(int n);
+
+/* a6  compute_hessian_chol  (sleekit/obq.py:38-55)
+ *     A: output of slk_hessian_prepare (destroyed).  U: n x n float64 row-major,
+ *     upper triangular with U^T U = Hd[order][:, order]^-1, zeros below the diagonal.
+ *     info[0] = 0 on success, else 1 + the (permuted) column where a non-positive
+ *     pivot appeared -- the reference raises numpy.linalg.LinAlgError there.    */
+int slk_chol_inverse_upper(double *A, int n, double *U, int *info, void *workspace,
+                           size_t ws_bytes, slk_stream_t stream);
+
+/* a5+a8+a9+a10  quantize_opt without local search  (sleekit/obq.py:106-137, 202-213)
+ *     W: R x n float32.  scale: per-row divisor applied on load (NULL: W is used as is).
+ *     Runs the blocked column-sequential loop in the order `order` with factor U and
+ *     the reference's recursion (min_block, num_blocks), float64 updates rounded to
+ *     float32 at the reference's rounding points.
+ *     Q (R x n float32, original column order): codebook VALUES in the scaled domain.
+ *     idx (may be NULL): codebook indices, uint8, original column order.       */
+int slk_gptq_quantize(const float *W, const float *scale, const long long *order, const double *U,
+                      int R, int n, int levels, float lo, float hi, int min_block, int num_blocks,
+                      float *Q, uint8_t *idx, void *workspace, size_t ws_bytes, slk_stream_t stream);
+
+/* a11 channelwise_error  (sleekit/obq.py:89-95): row_err[r] = (W-Q)[r] H (W-Q)[r]^T.
+ *     G (may be NULL): the R x n product (W - Q) @ H, reused by the local search. */
+int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n, float *row_err,
+                   float *G, slk_stream_t stream);
+
+/* a12+a13 quantize_local_search  (sleekit/obq.py:220-358)
+ *     W, Q: R x n float32 in the scaled domain; Q is updated in place, idx
+ *     (may be NULL) receives the indices of the result.  `moves` best-first
+ *     single-weight moves per row.                                             */
+int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, float lo,
+                     float hi, int moves, uint8_t *idx, void *workspace, size_t ws_bytes,
+                     slk_stream_t stream);
+
+/* Diagnostics used by tests ------------------------------------------------ */
+/* NumPy-ordered float32 mean of diag(H) -> out[0]. */
+int slk_diag_mean(const float *H, int n, float *out, void *workspace, size_t ws_bytes,
+                  slk_stream_t stream);
+/* Pure float64 MFMA throughput probe: returns after enqueuing `iters` MFMAs per wave. */
+int slk_probe_mfma_f64(double *sink, int blocks, int iters, slk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLEEKIT_AMD_H */

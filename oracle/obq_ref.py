@@ -1,0 +1,265 @@
+"""Oracle: GPTQ/OBQ column-sequential quantization with error propagation.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Restates the hot path of the reference `sleekit/obq.py`:
+
+    strip_input_mean      obq.py:14-25    (remove_input_bias)
+    patch_dead_columns    obq.py:28-35    (remove_dead_values)
+    inverse_factor_upper  obq.py:38-55    (compute_hessian_chol)
+    column_order          obq.py:58-86    (compute_hessian_order; diag/err/sqerr/none)
+    row_errors/mean_error obq.py:89-103   (channelwise_error/quantization_error)
+    block_schedule        obq.py:121-137  (the recursion of _quantize_opt_block, flattened)
+    run_schedule          obq.py:106-137  (_quantize_opt_core + block updates)
+    quantize_layer        obq.py:169-217  (quantize_opt)
+    flip_gains            obq.py:220-231  (compute_gain)
+    local_search          obq.py:234-358  (LocalSearchQuantizer + quantize_local_search)
+
+The reference recurses over views; here the recursion is flattened once into
+an explicit list of operations on absolute column ranges.  Every operation
+touches exactly the same memory with the same NumPy call as the reference, so
+the results are bit-identical (checked in tests/test_oracle_golden.py).
+
+Mixed precision that is part of the semantics (NumPy >= 2, NEP 50):
+  * `np.eye` makes the damped Hessian, hence the factor `U`, float64;
+  * `err = (w - q) / U[i, i]` is therefore float64 and so are both updates,
+    while `Q` and `E` are float32 stores (one rounding per update).
+"""
+
+import numpy as np
+
+LEAF = 0
+UPDATE = 1
+
+
+# --------------------------------------------------------------------------
+# Hessian preparation
+# --------------------------------------------------------------------------
+def strip_input_mean(H, mean):
+    """H - m m^T: the part of the Hessian a bias correction absorbs (obq.py:14-25)."""
+    assert H.ndim == 2 and mean.ndim == 1
+    assert H.shape[0] == H.shape[1] == mean.shape[0]
+    return H - np.outer(mean, mean)
+
+
+def patch_dead_columns(H, W):
+    """In place (obq.py:28-35): inputs that never fired get the mean diagonal and zero weights."""
+    diag = H.diagonal()
+    fill = diag.mean()
+    dead = diag == 0
+    H[dead, dead] = fill
+    W[:, dead] = 0
+
+
+def inverse_factor_upper(H):
+    """Upper-triangular U with U^T U = H^-1 (obq.py:38-55).
+
+    Cholesky of the index-reversed matrix, inverted, reversed back.
+    Raises numpy.linalg.LinAlgError when H is not positive definite.
+    """
+    R = np.flip(H)
+    R = np.linalg.cholesky(R)
+    R = np.linalg.inv(R)
+    return np.ascontiguousarray(np.flip(R))
+
+
+def column_order(W, H, grid, mode):
+    """Column processing order (obq.py:58-86), restricted to the hot-path modes."""
+    if mode == "diag":
+        return (-H.diagonal()).argsort()
+    if mode == "none":
+        return np.arange(W.shape[1])
+    if mode == "err":
+        miss = np.abs(grid(W) - W).sum(axis=0)
+        return (-H.diagonal() * miss).argsort()
+    if mode == "sqerr":
+        miss = np.square(grid(W) - W).sum(axis=0)
+        return (-H.diagonal() * miss).argsort()
+    raise RuntimeError(f"Invalid act_order value {mode}")
+
+
+# --------------------------------------------------------------------------
+# Error metric
+# --------------------------------------------------------------------------
+def row_errors(W, Q, H):
+    """(W-Q) H (W-Q)^T per output row (obq.py:89-95)."""
+    D = W - Q
+    return ((D @ H) * D).sum(axis=-1)
+
+
+def mean_error(W, Q, H):
+    """Layer error: mean over rows (obq.py:98-103)."""
+    return row_errors(W, Q, H).mean()
+
+
+# --------------------------------------------------------------------------
+# The column-sequential loop
+# --------------------------------------------------------------------------
+def block_schedule(width, min_block=32, num_blocks=8):
+    """Flatten the recursion of obq.py:121-137 into a list of operations.
+
+    Returns tuples
+        (LEAF,   c0, c1, 0)   quantize columns [c0, c1) one by one (obq.py:106-118)
+        (UPDATE, k0, k1, j1)  Q[:, k1:j1] -= E[:, k0:k1] @ U[k0:k1, k1:j1]   (obq.py:137)
+    in execution order, on absolute column indices.  Updates whose target
+    range is empty (the last block of every level) are dropped: the reference
+    executes them as no-ops on zero-width views.
+    """
+    assert min_block >= 1
+    ops = []
+    # Explicit stack of (start, stop) ranges still to be expanded; a range
+    # [a, b) lives inside its parent [pa, pb) whose end bounds its update.
+    def expand(a, b):
+        size = b - a
+        if size <= min_block:
+            ops.append((LEAF, a, b, 0))
+            return
+        step = max((size + num_blocks - 1) // num_blocks, min_block)
+        for s in range(a, b, step):
+            e = min(s + step, b)
+            expand(s, e)
+            if e < b:
+                ops.append((UPDATE, s, e, b))
+
+    expand(0, width)
+    return ops
+
+
+def run_schedule(Q, E, U, grid, ops):
+    """Execute a schedule in place on Q (float32 weights -> grid values) and E (errors)."""
+    for kind, a, b, c in ops:
+        if kind == LEAF:
+            for i in range(a, b):
+                w = Q[:, i]
+                q = grid(w)
+                err = (w - q) / U[i, i]
+                E[:, i] = err
+                Q[:, i] = q
+                Q[:, i + 1 : b] -= np.outer(err, U[i, i + 1 : b])
+        else:
+            Q[:, b:c] -= E[:, a:b] @ U[a:b, b:c]
+
+
+def quantize_layer(
+    W, H, grid, order_mode="diag", damp=0.01, ls_moves=0, min_block=32, num_blocks=8
+):
+    """GPTQ-style quantization of one layer (obq.py:169-217). Returns grid values, float32."""
+    assert W.ndim == 2 and H.ndim == 2
+    assert H.shape[0] == H.shape[1] == W.shape[1]
+    assert min_block >= 1
+    W = W.astype(np.float32)
+    H = H.astype(np.float32)
+    n = H.shape[0]
+
+    H_damped = H + damp * H.diagonal().mean() * np.eye(n)
+    order = column_order(W, H_damped, grid, order_mode)
+
+    Wp = W[:, order]
+    Q = Wp.copy()
+    H_damped = H_damped[order][:, order]
+    U = inverse_factor_upper(H_damped)
+
+    E = np.zeros_like(Wp)
+    run_schedule(Q, E, U, grid, block_schedule(n, min_block, num_blocks))
+
+    back = np.argsort(order)
+    W0 = Wp[:, back]
+    Q = Q[:, back]
+    return local_search(W0, Q, H, grid, ls_moves)
+
+
+def quantize_layer_debug(W, H, grid, order_mode="diag", damp=0.01, min_block=32, num_blocks=8):
+    """Same as quantize_layer without local search, also returning order, U and E (permuted)."""
+    W = W.astype(np.float32)
+    H = H.astype(np.float32)
+    n = H.shape[0]
+    H_damped = H + damp * H.diagonal().mean() * np.eye(n)
+    order = column_order(W, H_damped, grid, order_mode)
+    Wp = W[:, order]
+    Q = Wp.copy()
+    H_damped = H_damped[order][:, order]
+    U = inverse_factor_upper(H_damped)
+    E = np.zeros_like(Wp)
+    run_schedule(Q, E, U, grid, block_schedule(n, min_block, num_blocks))
+    return Q[:, np.argsort(order)], order, U, E
+
+
+# --------------------------------------------------------------------------
+# Local search
+# --------------------------------------------------------------------------
+def flip_gains(W, Q, H, candidates):
+    """Error decrease from moving each weight alone to its candidate (obq.py:220-231)."""
+    delta = Q - W
+    D = candidates - Q
+    return -np.square(D) * H.diagonal() - 2 * (delta @ H) * D
+
+
+class _SearchState:
+    """Per-row best-first search state (obq.py:234-346)."""
+
+    def __init__(self, W, Q, H, grid):
+        assert W.ndim == 2 and H.ndim == 2
+        assert H.shape[0] == H.shape[1] == W.shape[1]
+        assert Q.shape == W.shape
+        self.W, self.H, self.grid = W, H, grid
+        self.Q = Q.copy()
+        self.err = row_errors(W, self.Q, H)
+        self.cand = {+1: grid.quantize_up(self.Q), -1: grid.quantize_down(self.Q)}
+        self.gain = {s: flip_gains(W, self.Q, H, self.cand[s]) for s in (+1, -1)}
+
+    def _refresh(self, sign, rows, cols, q_old, c_old):
+        """Incremental gain update after Q[rows, cols] changed (obq.py:299-336)."""
+        gains, cand = self.gain[sign], self.cand[sign]
+        k = np.arange(len(rows))
+        H = self.H
+        Wr = self.W[rows].copy()
+        Q_new = self.Q[rows].copy()
+        Q_old = Q_new.copy()
+        Q_old[k, cols] = q_old
+        C_new = cand[rows].copy()
+        D_new = C_new - Q_new
+        Hr = H[cols].copy()
+
+        c_new, q_new = C_new[k, cols], Q_new[k, cols]
+        d_old, d_new = c_old - q_old, c_new - q_new
+        hd = H.diagonal()[cols]
+
+        gains[rows, cols] += hd * (np.square(d_old) - np.square(d_new))
+        gains[rows, cols] += 2 * ((Q_old - Wr) * Hr).sum(axis=-1) * (d_old - d_new)
+        gains[rows] += 2 * np.expand_dims(q_old - q_new, 1) * Hr * D_new
+
+    def _apply(self, sign, mask):
+        """Move the best weight of every selected row one step (obq.py:264-297)."""
+        gains, cand = self.gain[sign], self.cand[sign]
+        rows = np.arange(self.W.shape[0])[mask]
+        delta = gains.max(axis=1)[mask]
+        cols = gains.argmax(axis=1)[mask]
+        new = cand[rows, cols]
+        q_old = self.Q[rows, cols].copy()
+        self.Q[rows, cols] = new
+        up_old = self.cand[+1][rows, cols].copy()
+        self.cand[+1][rows, cols] = self.grid.quantize_up(new)
+        down_old = self.cand[-1][rows, cols].copy()
+        self.cand[-1][rows, cols] = self.grid.quantize_down(new)
+        self.err[rows] -= delta
+        self._refresh(+1, rows, cols, q_old, up_old)
+        self._refresh(-1, rows, cols, q_old, down_old)
+
+    def move(self):
+        """One move per row: the better of best-up / best-down if it helps (obq.py:338-346)."""
+        best_up = self.gain[+1].max(axis=1)
+        best_down = self.gain[-1].max(axis=1)
+        go_up = (best_up > best_down) & (best_up > 0)
+        go_down = ~go_up & (best_down > 0)
+        self._apply(+1, go_up)
+        self._apply(-1, go_down)
+
+
+def local_search(W, Q, H, grid, moves):
+    """obq.py:349-358: returns the input object itself when moves == 0."""
+    if moves == 0:
+        return Q
+    state = _SearchState(W, Q, H, grid)
+    for _ in range(moves):
+        state.move()
+    return state.Q

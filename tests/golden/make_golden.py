@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by running the REAL reference (Coloquinte/sleekit).
+
+Run only in the build container, where the reference is mounted read-only:
+
+    python tests/golden/make_golden.py [--large]
+
+It imports `sleekit` from /root/reference, feeds it layers from the build's own
+integer-hash generator (sleekit_amd/synth.py) and stores inputs' hashes and the
+reference's outputs:
+
+    small_cases.npz   full outputs (u8 indices, order, row errors, ...) of small layers
+    pieces.npz        known-answer vectors of the helper functions on the path
+    large_cases.json  SHA-256 of indices + float32 errors of BASELINE-sized layers
+
+Only data is written: inputs and expected outputs.  No reference source text is
+copied.  The fixtures record the NumPy/BLAS versions because the float64
+promotion in the reference (np.eye -> float64 factor) is NumPy >= 2 behaviour.
+"""
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+
+from sleekit_amd import synth  # noqa: E402
+
+import sleekit.obq as ref_obq  # noqa: E402
+import sleekit.scaling as ref_scaling  # noqa: E402
+from sleekit.codebook import UniformCodebook  # noqa: E402
+
+
+def sha(a):
+    a = np.ascontiguousarray(a)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def run_reference(L, levels, order, damp, moves, strip_mean=False):
+    cb = UniformCodebook(levels, -1, 1)
+    W, H, sc = L["W"], L["H"], L["scale"]
+    if strip_mean:
+        H = ref_obq.remove_input_bias(H, L["mean"])
+    out = ref_scaling.quantize_with_scaling(W, sc, cb, H, act_order=order, damp=damp, nb_ls_moves=moves)
+    idx = cb.quantize_index(ref_scaling.apply_scaling(out, sc, 0))
+    rows = ref_obq.channelwise_error(W, out, H)
+    return dict(out=out, idx=idx, row_err=rows, err=ref_obq.quantization_error(W, out, H), H_used=H)
+
+
+def small_cases():
+    store = {}
+    names = []
+    shapes = [(8, 16), (64, 96), (128, 256), (96, 172)]
+    seed = 2000
+    for R, n in shapes:
+        L = synth.make_layer(R, n, seed)
+        for levels in (2, 3, 4, 8):
+            for order in ("diag", "none", "sqerr"):
+                for moves in (0, 10):
+                    name = f"r{R}_n{n}_s{seed}_N{levels}_{order}_ls{moves}"
+                    r = run_reference(L, levels, order, 0.01, moves)
+                    store[name + "/idx"] = r["idx"]
+                    store[name + "/row_err"] = r["row_err"]
+                    store[name + "/err"] = np.float32(r["err"])
+                    names.append(name)
+        store[f"inputs_r{R}_n{n}_s{seed}/sha"] = np.array(
+            [sha(L["W"]), sha(L["H"]), sha(L["mean"]), sha(L["scale"])]
+        )
+        seed += 1
+    # one mid-sized layer, the experiment defaults only
+    R, n, seed = 256, 768, 2010
+    L = synth.make_layer(R, n, seed)
+    for levels in (3, 8):
+        for moves in (0, 10):
+            name = f"r{R}_n{n}_s{seed}_N{levels}_diag_ls{moves}"
+            r = run_reference(L, levels, "diag", 0.01, moves)
+            store[name + "/idx"] = r["idx"]
+            store[name + "/row_err"] = r["row_err"]
+            store[name + "/err"] = np.float32(r["err"])
+            names.append(name)
+    store[f"inputs_r{R}_n{n}_s{seed}/sha"] = np.array([sha(L["W"]), sha(L["H"]), sha(L["mean"]), sha(L["scale"])])
+    # bias-corrected Hessian (cfg3 style), damp 0.03, err ordering
+    R, n, seed = 64, 96, 2001
+    L = synth.make_layer(R, n, seed)
+    for levels, order, damp in ((3, "diag", 0.01), (8, "err", 0.03), (4, "sqerr", 0.03)):
+        name = f"r{R}_n{n}_s{seed}_N{levels}_{order}_ls0_strip_d{damp}"
+        r = run_reference(L, levels, order, damp, 0, strip_mean=True)
+        store[name + "/idx"] = r["idx"]
+        store[name + "/row_err"] = r["row_err"]
+        store[name + "/err"] = np.float32(r["err"])
+        names.append(name)
+    store["names"] = np.array(names)
+    return store
+
+
+def pieces():
+    """Known-answer vectors of the individual functions on the path."""
+    P = {}
+    # --- uniform codebook (codebook.py:43-95) on crafted float32 inputs ---
+    x = np.concatenate(
+        [
+            np.linspace(-1.5, 1.5, 4001, dtype=np.float32),
+            np.array([-1, 1, 0, -0.0, 1 / 7, 3 / 7, 0.5, -0.5, 1e-8, -1e-8, 0.14285713, 0.14285716], dtype=np.float32),
+            (synth.normal_grid(7, 9, 1, 4096)[0] * 0.6).astype(np.float32),
+        ]
+    )
+    P["cb/x"] = x
+    for levels in (2, 3, 4, 8, 16, 256):
+        cb = UniformCodebook(levels, -1, 1)
+        P[f"cb/N{levels}/value"] = cb.quantize_value(x)
+        P[f"cb/N{levels}/index"] = cb.quantize_index(x)
+        P[f"cb/N{levels}/up"] = cb.quantize_up(x)
+        P[f"cb/N{levels}/down"] = cb.quantize_down(x)
+    cb = UniformCodebook(5, -0.75, 1.25)  # asymmetric grid
+    for k in ("value", "index", "up", "down"):
+        P[f"cb/asym/{k}"] = getattr(cb, "quantize_" + k)(x)
+
+    # --- Hessian preparation + factor + full debug trace on one tiny layer ---
+    L = synth.make_layer(8, 16, 2000)
+    W, H = L["W"].copy(), L["H"].copy()
+    cb = UniformCodebook(8, -1, 1)
+    Ws = ref_scaling.apply_scaling(W, L["scale"], 0)
+    Hd = H.astype(np.float32) + 0.01 * H.diagonal().mean() * np.eye(16)
+    order = ref_obq.compute_hessian_order(Ws, Hd, cb, "diag")
+    U = ref_obq.compute_hessian_chol(Hd[order][:, order])
+    Q = Ws[:, order].copy()
+    E = np.zeros_like(Q)
+    ref_obq._quantize_opt_block(Q, E, U, cb, 4, 2)  # small blocks: exercises 3 recursion levels
+    P["trace/order"], P["trace/U"], P["trace/Q"], P["trace/E"] = order, U, Q, E
+    P["trace/Hd_diag"] = Hd.diagonal().copy()
+
+    # --- dead columns and input-mean removal (obq.py:14-35) ---
+    L = synth.make_layer(32, 64, 2020, dead=(3, 17, 40))
+    Hx, Wx = L["H"].copy(), L["W"].copy()
+    ref_obq.remove_dead_values(Hx, Wx)
+    P["dead/H"], P["dead/W"] = Hx, Wx
+    P["strip/H"] = ref_obq.remove_input_bias(L["H"], L["mean"])
+    cb = UniformCodebook(8, -1, 1)
+    out = ref_scaling.quantize_with_scaling(Wx, L["scale"], cb, Hx)
+    P["dead/idx"] = cb.quantize_index(ref_scaling.apply_scaling(out, L["scale"], 0))
+    P["dead/err"] = np.float32(ref_obq.quantization_error(Wx, out, Hx))
+
+    # --- scale helpers (scaling.py:21-55) ---
+    L = synth.make_layer(64, 96, 2001)
+    cb = UniformCodebook(8, -1, 1)
+    P["scale/noclip"] = ref_scaling.compute_non_saturating_scaling(L["W"], cb, 0)
+    P["scale/norm"] = ref_scaling.compute_norm_scaling(L["W"], 0)
+    P["scale/apply"] = ref_scaling.apply_scaling(L["W"], L["scale"], 0)
+    P["scale/rtn"] = ref_scaling.quantize_with_scaling(L["W"], L["scale"], cb)
+    for mode in ("mse", "diag", "hessian", "diag3", "hessian1"):
+        P[f"scale/search_{mode}"] = ref_scaling.compute_scaling(L["W"], cb, L["H"], mode=mode, grid_size=20)
+    P["scale/search_obq"] = ref_scaling.compute_scaling(L["W"], cb, L["H"], mode="obq", grid_size=10)
+
+    # --- gains (obq.py:220-231) ---
+    Q0 = cb(ref_scaling.apply_scaling(L["W"], L["scale"], 0))
+    Ws = ref_scaling.apply_scaling(L["W"], L["scale"], 0)
+    P["gain/up"] = ref_obq.compute_gain(Ws, Q0, L["H"], cb.quantize_up(Q0))
+    P["gain/down"] = ref_obq.compute_gain(Ws, Q0, L["H"], cb.quantize_down(Q0))
+
+    # --- running statistics (statistics.py:76-87) through the real torch adapter ---
+    import torch
+    from sleekit import Sleekit
+
+    lin = torch.nn.Linear(48, 10)
+    st = Sleekit(lin)
+    X = synth.make_activations(200, 48, 2030).astype(np.float32)
+    for a, b in ((0, 64), (64, 72), (72, 200)):
+        st.add_batch(torch.from_numpy(X[a:b]).reshape(1, b - a, 48))
+    P["stats/X"], P["stats/H"], P["stats/mean"] = X, st.hessian.numpy().copy(), st.mean.numpy().copy()
+    P["stats/count"] = np.int64(st.count)
+    return P
+
+
+LARGE = [
+    # (R, n, seed, levels, order, damp, moves, strip_mean)
+    (768, 768, 1000, 8, "diag", 0.01, 0, False),  # cfg1 / OPT-125M attention
+    (3072, 768, 1001, 8, "diag", 0.01, 0, False),  # OPT-125M fc1
+    (768, 3072, 1002, 8, "diag", 0.01, 0, False),  # OPT-125M fc2
+    (1024, 1024, 1003, 3, "diag", 0.01, 0, True),  # cfg3: 1.5 bit + bias-corrected H
+    (1024, 4096, 1004, 3, "diag", 0.01, 0, True),
+    (1024, 1024, 1005, 8, "diag", 0.01, 10, False),  # cfg4: 3 bit + 10 moves
+    (4096, 1024, 1006, 8, "diag", 0.01, 10, False),
+    (4096, 4096, 1007, 8, "diag", 0.01, 0, False),  # headline
+    (512, 11008, 1008, 4, "diag", 0.01, 0, False),  # cfg5 row shard (1/8 of 4096 rows)
+]
+
+
+def large_cases(selected=None):
+    out = []
+    for spec in LARGE:
+        R, n, seed, levels, order, damp, moves, strip = spec
+        if selected and f"{R}x{n}" not in selected:
+            continue
+        t0 = time.time()
+        L = synth.make_layer(R, n, seed)
+        t1 = time.time()
+        r = run_reference(L, levels, order, damp, moves, strip_mean=strip)
+        t2 = time.time()
+        rec = dict(
+            R=R, n=n, seed=seed, levels=levels, order=order, damp=damp, moves=moves, strip_mean=strip,
+            sha_W=sha(L["W"]), sha_H=sha(L["H"]), sha_mean=sha(L["mean"]), sha_scale=sha(L["scale"]),
+            sha_idx=sha(r["idx"]), err_f32_hex=np.float32(r["err"]).tobytes().hex(), err=float(r["err"]),
+            idx_histogram=np.bincount(r["idx"].ravel(), minlength=levels).tolist(),
+            gen_seconds=round(t1 - t0, 2), reference_seconds=round(t2 - t1, 2),
+        )
+        print(rec, flush=True)
+        out.append(rec)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--large", action="store_true", help="also (re)generate large_cases.json (minutes)")
+    ap.add_argument("--only", nargs="*", help="large shapes to run, e.g. 768x768")
+    args = ap.parse_args()
+
+    env = dict(numpy=np.__version__, python=sys.version.split()[0], cpu_count=os.cpu_count())
+    try:
+        env["blas"] = np.show_config(mode="dicts")["Build Dependencies"]["blas"]["openblas configuration"]
+    except Exception:
+        env["blas"] = "unknown"
+
+    np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **small_cases())
+    np.savez_compressed(os.path.join(HERE, "pieces.npz"), **pieces())
+    with open(os.path.join(HERE, "environment.json"), "w") as f:
+        json.dump(env, f, indent=1)
+    if args.large:
+        path = os.path.join(HERE, "large_cases.json")
+        recs = large_cases(args.only)
+        if args.only and os.path.exists(path):
+            old = {(r["R"], r["n"], r["seed"]): r for r in json.load(open(path))["cases"]}
+            old.update({(r["R"], r["n"], r["seed"]): r for r in recs})
+            recs = list(old.values())
+        with open(path, "w") as f:
+            json.dump(dict(environment=env, cases=recs), f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,7 @@ size_t slk_workspace_bytes(int R, int n);
 
 /* a7  UniformCodebook.quantize_value/index/up/down  (sleekit/codebook.py:43-95)
  *     out[i] = map(x[i]); float32 arithmetic, IEEE divide, round-half-even.    */
-int slk_codebook_apply(const float *x, size_t count, int levels, float lo, float hi, int what,
+int slk_codebook_apply(const float *x, size_t count, int levels, double lo, double hi, int what,
                        void *out, slk_stream_t stream);
 
 /* a14 apply_scaling on axis 0  (sleekit/scaling.py:21-25, 73, 80)
@@ -86,7 +86,7 @@ int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T,
 
 /* a4  column statistics for the err / sqerr orders  (sleekit/obq.py:60-69)
  *     miss[j] = sum over rows, in row order, of |q(W) - W| (squared == 0) or its square. */
-int slk_column_miss(const float *W, int R, int n, int levels, float lo, float hi, int squared,
+int slk_column_miss(const float *W, int R, int n, int levels, double lo, double hi, int squared,
                     float *miss, slk_stream_t stream);
 
 /* a3+a4+a5  damping, ordering, permutation  (sleekit/obq.py:198-204)
@@ -100,6 +100,9 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
                         slk_stream_t stream);
 /* Leading dimension (and row count) of the padded float64 matrices A / scratch. */
 int slk_factor_ld(int n);
+/* Same layout from a float64 matrix as is (no damping, no order): A = reversed lower
+ * triangle of M, padded.  Entry for compute_hessian_chol on a caller's own matrix.  */
+int slk_factor_load(const double *M, int n, double *A, slk_stream_t stream);
 
 /* a6  compute_hessian_chol  (sleekit/obq.py:38-55)
  *     A: output of slk_hessian_prepare (destroyed).  U: n x n float64 row-major,
@@ -114,31 +117,36 @@ int slk_chol_inverse_upper(double *A, int n, double *U, int *info, void *workspa
  *     Runs the blocked column-sequential loop in the order `order` with factor U and
  *     the reference's recursion (min_block, num_blocks), float64 updates rounded to
  *     float32 at the reference's rounding points.
+ *     order (may be NULL): identity, i.e. _quantize_opt_block on Q as given (obq.py:121-137).
  *     Q (R x n float32, original column order): codebook VALUES in the scaled domain.
- *     idx (may be NULL): codebook indices, uint8, original column order.       */
+ *     idx (may be NULL): codebook indices, uint8, original column order.
+ *     E_out (may be NULL): the scaled errors E of obq.py:115, R x n, in PROCESSING order. */
 int slk_gptq_quantize(const float *W, const float *scale, const long long *order, const double *U,
-                      int R, int n, int levels, float lo, float hi, int min_block, int num_blocks,
-                      float *Q, uint8_t *idx, void *workspace, size_t ws_bytes, slk_stream_t stream);
+                      int R, int n, int levels, double lo, double hi, int min_block, int num_blocks,
+                      float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
+                      slk_stream_t stream);
 
 /* a11 channelwise_error  (sleekit/obq.py:89-95): row_err[r] = (W-Q)[r] H (W-Q)[r]^T.
  *     G (may be NULL): the R x n product (W - Q) @ H, reused by the local search. */
 int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n, float *row_err,
-                   float *G, slk_stream_t stream);
+                   float *G, void *workspace, size_t ws_bytes, slk_stream_t stream);
 
 /* a12+a13 quantize_local_search  (sleekit/obq.py:220-358)
  *     W, Q: R x n float32 in the scaled domain; Q is updated in place, idx
  *     (may be NULL) receives the indices of the result.  `moves` best-first
  *     single-weight moves per row.                                             */
-int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, float lo,
-                     float hi, int moves, uint8_t *idx, void *workspace, size_t ws_bytes,
+int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
+                     double hi, int moves, uint8_t *idx, void *workspace, size_t ws_bytes,
                      slk_stream_t stream);
 
 /* Diagnostics used by tests ------------------------------------------------ */
 /* NumPy-ordered float32 mean of diag(H) -> out[0]. */
 int slk_diag_mean(const float *H, int n, float *out, void *workspace, size_t ws_bytes,
                   slk_stream_t stream);
-/* Pure float64 MFMA throughput probe: returns after enqueuing `iters` MFMAs per wave. */
+/* Peak probes: every wave of `blocks` 256-thread workgroups issues `iters` x 4 independent
+ * v_mfma_f64_16x16x4_f64 (2048 flop each) / v_mfma_f32_32x32x2_f32 (4096 flop each).      */
 int slk_probe_mfma_f64(double *sink, int blocks, int iters, slk_stream_t stream);
+int slk_probe_mfma_f32(float *sink, int blocks, int iters, slk_stream_t stream);
 
 #ifdef __cplusplus
 }

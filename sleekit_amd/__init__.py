@@ -1,1 +1,21 @@
-"""sleekit_amd: MI355X-native GPTQ/OBQ layer quantization behind the sleekit function surface."""
+"""sleekit_amd: MI355X-native GPTQ/OBQ layer quantization behind the sleekit function surface.
+
+    from sleekit_amd import obq, scaling, codebook, Sleekit
+
+mirrors `sleekit.obq`, `sleekit.scaling`, `sleekit.codebook` and `sleekit.Sleekit` of
+Coloquinte/sleekit for the hot path.  Submodules are imported lazily
+so that `sleekit_amd.synth` (pure NumPy test-data generation) stays importable before the
+HIP library is built; everything else needs libsleekit_amd.so and fails loudly without it.
+"""
+
+import importlib
+
+_SUBMODULES = ("codebook", "obq", "scaling", "statistics", "engine", "dist", "synth", "_lib", "_device")
+
+
+def __getattr__(name):
+    if name in _SUBMODULES:
+        return importlib.import_module(f"{__name__}.{name}")
+    if name == "Sleekit":
+        return importlib.import_module(f"{__name__}.statistics").Sleekit
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -1,0 +1,93 @@
+"""Device plumbing: torch-ROCm owns memory and streams, the HIP library does the work.
+
+Functions of the public modules accept NumPy arrays (the reference's calling convention:
+arrays in, new arrays out) or torch tensors already resident on the GPU (nothing leaves
+HBM, nothing synchronises).
+"""
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_workspaces = {}
+
+# When True, data-dependent failures (a non-positive pivot in the factorisation) are not
+# checked after each call -- that check is a device->host read and a stream sync.  The
+# pending status words can be checked later with `raise_pending()`.
+lazy_errors = False
+_pending_info = []
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "sleekit_amd needs an AMD GPU (built for gfx950 / MI355X) visible to torch; there is no CPU fallback"
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_handle():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def is_device_tensor(x):
+    return isinstance(x, torch.Tensor) and x.is_cuda
+
+
+def to_device(x, dtype=torch.float32):
+    """NumPy array / CPU tensor / device tensor -> contiguous device tensor of `dtype`."""
+    dev = require_gpu()
+    if isinstance(x, torch.Tensor):
+        return x.to(device=dev, dtype=dtype).contiguous()
+    a = np.ascontiguousarray(x)
+    return torch.from_numpy(a).to(device=dev, dtype=dtype).contiguous()
+
+
+def like_input(t, template):
+    """Return `t` the way `template` came in: NumPy for NumPy, device tensor for device tensor."""
+    if is_device_tensor(template):
+        return t
+    if isinstance(template, torch.Tensor):
+        return t.cpu()
+    return t.cpu().numpy()
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def workspace(R, n):
+    """(tensor, bytes): grow-only scratch per (device, stream) sized by slk_workspace_bytes."""
+    dev = require_gpu()
+    need = int(_lib.lib.slk_workspace_bytes(int(R), int(n)))
+    key = (dev.index, stream_handle())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws, ws.numel()
+
+
+def release_workspaces():
+    _workspaces.clear()
+
+
+def note_info(info, what):
+    """Register the status word of a factorisation; raise now unless lazy_errors is set."""
+    if lazy_errors:
+        _pending_info.append((info, what))
+        return
+    _raise_if_failed(info, what)
+
+
+def _raise_if_failed(info, what):
+    code = int(info.item())
+    if code != 0:
+        raise np.linalg.LinAlgError(f"{what}: Matrix is not positive definite (pivot {code - 1})")
+
+
+def raise_pending():
+    pending, _pending_info[:] = list(_pending_info), []
+    for info, what in pending:
+        _raise_if_failed(info, what)

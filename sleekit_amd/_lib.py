@@ -1,0 +1,73 @@
+"""ctypes binding of libsleekit_amd.so (the C ABI declared in include/sleekit_amd.h).
+
+There is no CPU path: if the library has not been built, importing this module
+raises; if no MI355X is visible, the first call that needs the device raises.
+"""
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsleekit_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C sleekit_amd/csrc` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`). sleekit_amd has no CPU fallback."
+    )
+
+lib = ctypes.CDLL(LIB_PATH)
+
+OK, E_ARG, E_NOT_PD, E_HIP, E_WS = 0, -1, -2, -3, -4
+CB_VALUE, CB_INDEX, CB_UP, CB_DOWN = 0, 1, 2, 3
+ORDER_NONE, ORDER_DIAG, ORDER_ERR, ORDER_SQERR = 0, 1, 2, 3
+ORDER_MODES = {"none": ORDER_NONE, "diag": ORDER_DIAG, "err": ORDER_ERR, "sqerr": ORDER_SQERR}
+
+P = c_void_p  # device pointers travel as plain addresses
+
+# name -> (restype, argtypes); every symbol of include/sleekit_amd.h is listed here and
+# tests/test_abi.py checks the two stay in step.
+PROTOTYPES = {
+    "slk_abi_version": (c_int, []),
+    "slk_last_error": (c_char_p, []),
+    "slk_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "slk_codebook_apply": (c_int, [P, c_size_t, c_int, c_double, c_double, c_int, P, P]),
+    "slk_rows_divide": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "slk_hessian_strip_mean": (c_int, [P, P, c_int, P, P]),
+    "slk_hessian_patch_dead": (c_int, [P, P, c_int, c_int, P, c_size_t, P]),
+    "slk_hessian_accumulate": (c_int, [P, P, P, c_int, c_int, c_longlong, P]),
+    "slk_column_miss": (c_int, [P, c_int, c_int, c_int, c_double, c_double, c_int, P, P]),
+    "slk_hessian_prepare": (c_int, [P, c_int, c_float, c_int, P, P, P, P, c_size_t, P]),
+    "slk_factor_ld": (c_int, [c_int]),
+    "slk_factor_load": (c_int, [P, c_int, P, P]),
+    "slk_chol_inverse_upper": (c_int, [P, c_int, P, P, P, c_size_t, P]),
+    "slk_gptq_quantize": (
+        c_int,
+        [P, P, P, P, c_int, c_int, c_int, c_double, c_double, c_int, c_int, P, P, P, P, c_size_t, P],
+    ),
+    "slk_row_errors": (c_int, [P, P, P, c_int, c_int, P, P, P, c_size_t, P]),
+    "slk_local_search": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_double, c_int, P, P, c_size_t, P]),
+    "slk_diag_mean": (c_int, [P, c_int, P, P, c_size_t, P]),
+    "slk_probe_mfma_f64": (c_int, [P, c_int, c_int, P]),
+    "slk_probe_mfma_f32": (c_int, [P, c_int, c_int, P]),
+}
+
+for _name, (_res, _args) in PROTOTYPES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library out of step
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class SleekitAmdError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """Turn a negative return code into an exception carrying slk_last_error()."""
+    if rc == OK:
+        return
+    msg = (lib.slk_last_error() or b"").decode("utf-8", "replace")
+    if rc == E_ARG:
+        raise RuntimeError(msg or "invalid argument")
+    raise SleekitAmdError(f"libsleekit_amd error {rc}: {msg}")

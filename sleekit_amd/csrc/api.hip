@@ -1,0 +1,71 @@
+// Workspace sizing and the MFMA peak probes used by bench.py to anchor the roofline.
+#include "mfma32.h"
+#include "mfma64.h"
+
+namespace slk {
+
+__global__ __launch_bounds__(256) void k_probe_f64(double *sink, int iters) {
+    double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    const double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, c3, 0, 0, 0);
+    }
+    const double4_t s = c0 + c1 + c2 + c3;
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678) sink[0] = s[0];  // keep the chain alive
+}
+
+__global__ __launch_bounds__(256) void k_probe_f32(float *sink, int iters) {
+    float16_t c0, c1, c2, c3;
+    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = c2[r] = c3[r] = 0.0f;
+    const float a = 1.0f + threadIdx.x * 1e-3f, b = 1.0f - threadIdx.x * 1e-3f;
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, c3, 0, 0, 0);
+    }
+    const float16_t s = c0 + c1 + c2 + c3;
+    float tot = 0.0f;
+    for (int r = 0; r < 16; ++r) tot += s[r];
+    if (tot == 12345.678f) sink[0] = tot;
+}
+
+}  // namespace slk
+
+using namespace slk;
+
+extern "C" {
+
+size_t slk_workspace_bytes(int R, int n) {
+    if (R < 0 || n <= 0) return 0;
+    const size_t ld = (size_t)slk_factor_ld(n);
+    const size_t rn = (size_t)(R > 0 ? R : 1) * (size_t)n;
+    size_t factor = 2 * ld * ld * sizeof(double);                      // X and S of slk_chol_inverse_upper
+    size_t loop = 2 * rn * sizeof(float) + (size_t)n * sizeof(int);    // permuted Q and E, inverse order
+    size_t search = rn * sizeof(float) + (size_t)(R + n) * sizeof(float) + (size_t)R * ((n + 127) / 128) * sizeof(float);
+    size_t prep = 64 * sizeof(float) + (size_t)n * (sizeof(double) + 1);
+    size_t m = factor;
+    if (loop > m) m = loop;
+    if (search > m) m = search;
+    if (prep > m) m = prep;
+    return m + (1u << 16);
+}
+
+int slk_probe_mfma_f64(double *sink, int blocks, int iters, slk_stream_t stream) {
+    SLK_REQUIRE(sink && blocks > 0 && iters > 0, "bad arguments");
+    k_probe_f64<<<blocks, 256, 0, as_stream(stream)>>>(sink, iters);
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}
+
+int slk_probe_mfma_f32(float *sink, int blocks, int iters, slk_stream_t stream) {
+    SLK_REQUIRE(sink && blocks > 0 && iters > 0, "bad arguments");
+    k_probe_f32<<<blocks, 256, 0, as_stream(stream)>>>(sink, iters);
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// Element-wise stages of the path: codebook maps, row scaling, Hessian fix-ups,
+// column statistics.  All HBM-bound streaming kernels: 16-byte loads where the
+// layout allows, grid-stride over at most 2048 blocks (guide: Guideline 11/13).
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace slk {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+static inline int stream_blocks(size_t work_items, int per_block) {
+    size_t b = (work_items + per_block - 1) / per_block;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------- codebook maps
+template <int WHAT>
+__global__ __launch_bounds__(256) void k_codebook(const float *__restrict__ x, size_t count, Grid g,
+                                                  void *__restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float v = x[i];
+        if (WHAT == SLK_CB_VALUE) {
+            static_cast<float *>(out)[i] = grid_value(v, g);
+        } else if (WHAT == SLK_CB_INDEX) {
+            static_cast<uint8_t *>(out)[i] = (uint8_t)grid_pos(v, g, 0.0f, 0.0f, g.top);
+        } else if (WHAT == SLK_CB_UP) {
+            static_cast<float *>(out)[i] = grid_val(grid_pos(v, g, 1.0f, 1.0f, g.top), g);
+        } else {
+            static_cast<float *>(out)[i] = grid_val(grid_pos(v, g, -1.0f, 0.0f, g.top - 1.0f), g);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- row scaling
+__global__ __launch_bounds__(256) void k_rows_divide(const float *__restrict__ x,
+                                                     const float *__restrict__ scale, int R, int n,
+                                                     int invert, float *__restrict__ out) {
+    // one block walks rows; threads walk columns (coalesced)
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        float s = scale[r];
+        if (invert) s = 1.0f / s;
+        const float *xr = x + (size_t)r * n;
+        float *orow = out + (size_t)r * n;
+        for (int j = threadIdx.x; j < n; j += blockDim.x) orow[j] = xr[j] / s;
+    }
+}
+
+// ---------------------------------------------------------------- H - m m^T
+__global__ __launch_bounds__(256) void k_strip_mean(const float *__restrict__ H,
+                                                    const float *__restrict__ mean, int n,
+                                                    float *__restrict__ out) {
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const float mi = mean[i];
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            const float p = mi * mean[j];  // np.outer in float32, then one subtraction
+            out[(size_t)i * n + j] = H[(size_t)i * n + j] - p;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- dead columns
+__global__ __launch_bounds__(256) void k_patch_dead(float *__restrict__ H, float *__restrict__ W,
+                                                    int R, int n, const float *__restrict__ fill,
+                                                    uint8_t *__restrict__ dead) {
+    // pass 1 (block 0 .. ): flag dead columns and patch the diagonal
+    const float f = fill[0];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const bool d = H[(size_t)j * n + j] == 0.0f;
+        dead[j] = d;
+        if (d) H[(size_t)j * n + j] = f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_zero_dead(float *__restrict__ W, int R, int n,
+                                                   const uint8_t *__restrict__ dead) {
+    for (int r = blockIdx.x; r < R; r += gridDim.x)
+        for (int j = threadIdx.x; j < n; j += blockDim.x)
+            if (dead[j]) W[(size_t)r * n + j] = 0.0f;
+}
+
+// ---------------------------------------------------------------- column miss
+// miss[j] = sum_r f(q(W[r][j]) - W[r][j]), accumulated in row order in float32
+// (NumPy's axis-0 reduction adds row after row).  One thread per column.
+__global__ __launch_bounds__(256) void k_column_miss(const float *__restrict__ W, int R, int n, Grid g,
+                                                     int squared, float *__restrict__ miss) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float acc = 0.0f;
+    for (int r = 0; r < R; ++r) {
+        const float w = W[(size_t)r * n + j];
+        const float d = grid_value(w, g) - w;
+        const float t = squared ? d * d : fabsf(d);
+        acc = acc + t;
+    }
+    miss[j] = acc;
+}
+
+}  // namespace slk
+
+using namespace slk;
+
+extern "C" {
+
+int slk_abi_version(void) { return 1; }
+
+const char *slk_last_error(void) { return g_error; }
+
+int slk_codebook_apply(const float *x, size_t count, int levels, double lo, double hi, int what,
+                       void *out, slk_stream_t stream) {
+    SLK_REQUIRE(levels >= 2 && lo < hi, "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(what >= 0 && what <= 3, "unknown codebook map %d", what);
+    SLK_REQUIRE(what != SLK_CB_INDEX || levels <= 256, "uint8 indices need levels <= 256");
+    if (count == 0) return SLK_OK;
+    SLK_REQUIRE(x && out, "null pointer");
+    const Grid g = make_grid(levels, lo, hi);
+    const int blocks = stream_blocks(count, 256 * 4);
+    hipStream_t s = as_stream(stream);
+    switch (what) {
+        case SLK_CB_VALUE: k_codebook<SLK_CB_VALUE><<<blocks, 256, 0, s>>>(x, count, g, out); break;
+        case SLK_CB_INDEX: k_codebook<SLK_CB_INDEX><<<blocks, 256, 0, s>>>(x, count, g, out); break;
+        case SLK_CB_UP: k_codebook<SLK_CB_UP><<<blocks, 256, 0, s>>>(x, count, g, out); break;
+        default: k_codebook<SLK_CB_DOWN><<<blocks, 256, 0, s>>>(x, count, g, out); break;
+    }
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}
+
+int slk_rows_divide(const float *x, const float *scale, int R, int n, int invert, float *out,
+                    slk_stream_t stream) {
+    SLK_REQUIRE(R >= 0 && n >= 0, "negative shape");
+    if (R == 0 || n == 0) return SLK_OK;
+    SLK_REQUIRE(x && scale && out, "null pointer");
+    k_rows_divide<<<stream_blocks(R, 1), 256, 0, as_stream(stream)>>>(x, scale, R, n, invert, out);
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}
+
+int slk_hessian_strip_mean(const float *H, const float *mean, int n, float *out, slk_stream_t stream) {
+    SLK_REQUIRE(n >= 0, "negative shape");
+    if (n == 0) return SLK_OK;
+    SLK_REQUIRE(H && mean && out, "null pointer");
+    k_strip_mean<<<stream_blocks(n, 1), 256, 0, as_stream(stream)>>>(H, mean, n, out);
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}
+
+int slk_hessian_patch_dead(float *H, float *W, int R, int n, void *workspace, size_t ws_bytes,
+                           slk_stream_t stream) {
+    SLK_REQUIRE(n > 0 && R >= 0 && H, "bad arguments");
+    Arena ws(workspace, ws_bytes);
+    float *fill = ws.take<float>(64);
+    uint8_t *dead = ws.take<uint8_t>((size_t)n);
+    if (!fill || !dead) {
+        set_error("workspace too small");
+        return SLK_E_WS;
+    }
+    size_t used = ws.used;
+    int rc = slk_diag_mean(H, n, fill, static_cast<char *>(workspace) + align_up(used, 256),
+                           ws_bytes - align_up(used, 256), stream);
+    if (rc != SLK_OK) return rc;
+    k_patch_dead<<<stream_blocks(n, 256), 256, 0, as_stream(stream)>>>(H, W, R, n, fill, dead);
+    SLK_LAUNCH_CHECK();
+    if (W && R > 0) {
+        k_zero_dead<<<stream_blocks(R, 1), 256, 0, as_stream(stream)>>>(W, R, n, dead);
+        SLK_LAUNCH_CHECK();
+    }
+    return SLK_OK;
+}
+
+int slk_column_miss(const float *W, int R, int n, int levels, double lo, double hi, int squared,
+                    float *miss, slk_stream_t stream) {
+    SLK_REQUIRE(levels >= 2 && lo < hi, "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(R >= 0 && n > 0 && W && miss, "bad arguments");
+    k_column_miss<<<(n + 255) / 256, 256, 0, as_stream(stream)>>>(W, R, n, make_grid(levels, lo, hi),
+                                                                  squared, miss);
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,309 @@
+// a5 + a8 + a9 + a10: the column-sequential quantize / error-propagation loop
+// (sleekit/obq.py:106-137, 202-213) with the reference's recursion and rounding points.
+//
+// Host side flattens the recursion of _quantize_opt_block into
+//   LEAF(a, b)        quantize columns a..b-1 one at a time           (obq.py:106-118)
+//   UPDATE(a, b, c)   Q[:, b:c] -= E[:, a:b] @ U[a:b, b:c]            (obq.py:137)
+// and cuts it into WINDOWS: maximal sub-trees at most 512 columns wide.  A window runs in
+// one kernel, a 16-row tile per workgroup with its Q and E columns resident in LDS; the
+// updates that reach beyond a window run as chip-wide float64 MFMA GEMMs.
+//
+// Numerics follow the reference exactly: float32 quantizer (true divide, rint, separate
+// multiply/add), err = float64(w - q) / U[i][i], rank-1 and block updates in float64
+// (product rounded, then subtraction rounded), one rounding to float32 per update.
+#include <vector>
+
+#include "mfma64.h"
+
+namespace slk {
+
+constexpr int OP_LEAF = 0, OP_UPDATE = 1;
+constexpr int WMAX = 512;     // widest window held in LDS
+constexpr int WPITCH = WMAX + 4;
+constexpr int RB = 16;        // rows per window workgroup
+constexpr int MAX_OPS = 60;   // ops per window kernel (kernel-argument table)
+constexpr int ULEAF = 32;     // leaves up to this width stage their U block in LDS
+
+struct Op {
+    int kind, a, b, c;
+};
+struct OpTable {
+    int count;
+    Op op[MAX_OPS];
+};
+
+// ------------------------------------------------------------------ permute in / out
+// Qp[r][c] = W[r][order[c]] (/ scale[r]);  E is cleared by the window kernels as they go.
+__global__ __launch_bounds__(256) void k_permute_in(const float *__restrict__ W, const float *__restrict__ scale,
+                                                    const long long *__restrict__ order, int R, int n,
+                                                    float *__restrict__ Qp, int *__restrict__ inv_order) {
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        const float *src = W + (size_t)r * n;
+        float *dst = Qp + (size_t)r * n;
+        if (scale) {
+            const float s = scale[r];
+            for (int c = threadIdx.x; c < n; c += blockDim.x) dst[c] = src[order ? order[c] : c] / s;
+        } else {
+            for (int c = threadIdx.x; c < n; c += blockDim.x) dst[c] = src[order ? order[c] : c];
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < n; c += blockDim.x) inv_order[order ? order[c] : c] = c;
+}
+
+// Q[r][j] = Qp[r][inv[j]];  idx[r][j] = grid index of that value (codebook.py:43-54).
+__global__ __launch_bounds__(256) void k_permute_out(const float *__restrict__ Qp, const int *__restrict__ inv_order,
+                                                     int R, int n, Grid g, float *__restrict__ Q,
+                                                     uint8_t *__restrict__ idx) {
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        const float *src = Qp + (size_t)r * n;
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            const float v = src[inv_order[j]];
+            Q[(size_t)r * n + j] = v;
+            if (idx) idx[(size_t)r * n + j] = (uint8_t)grid_pos(v, g, 0.0f, 0.0f, g.top);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ window kernel
+struct WindowSmem {
+    float q[RB][WPITCH];
+    float e[RB][WPITCH];
+    double u[ULEAF][ULEAF + 1];
+};
+
+// One workgroup = 512 threads = 8 waves = RB rows.  In a LEAF each wave owns two rows,
+// 32 lanes per row: lane c updates column i+1+c after column i is fixed.  In an UPDATE the
+// 8 waves split the target columns in 16-wide MFMA blocks (M = the 16 rows of the tile).
+template <bool IN_LDS>
+__global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, float *__restrict__ Eg,
+                                                     const double *__restrict__ U, int R, int n, int w0, int w1,
+                                                     Grid g, OpTable tab) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    WindowSmem &sm = *reinterpret_cast<WindowSmem *>(smem_raw);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r0 = blockIdx.x * RB;
+    const int width = w1 - w0;
+
+    // tile accessors: LDS copy of the window, or the global arrays themselves (very wide leaves)
+    auto qref = [&](int r, int c) -> volatile float & {
+        return IN_LDS ? *(volatile float *)&sm.q[r][c - w0] : *(volatile float *)&Qp[(size_t)(r0 + r) * n + c];
+    };
+    auto eref = [&](int r, int c) -> volatile float & {
+        return IN_LDS ? *(volatile float *)&sm.e[r][c - w0] : *(volatile float *)&Eg[(size_t)(r0 + r) * n + c];
+    };
+
+    if (IN_LDS) {
+        for (int e = t; e < RB * width; e += 512) {
+            const int r = e / width, c = e % width;
+            sm.q[r][c] = (r0 + r < R) ? Qp[(size_t)(r0 + r) * n + w0 + c] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    for (int oi = 0; oi < tab.count; ++oi) {
+        const Op op = tab.op[oi];
+        if (op.kind == OP_LEAF) {
+            const int a = op.a, b = op.b, w = b - a;
+            const bool staged = w <= ULEAF;
+            if (staged) {
+                for (int e = t; e < w * w; e += 512) {
+                    const int i = e / w, j = e % w;
+                    sm.u[i][j] = U[(size_t)(a + i) * n + a + j];
+                }
+            }
+            __syncthreads();
+            const int row = 2 * wave + (lane >> 5), l32 = lane & 31;
+            const bool live = IN_LDS || (r0 + row < R);
+            if (live) {
+                for (int i = a; i < b; ++i) {
+                    const float x = qref(row, i);
+                    const float q = grid_value(x, g);
+                    const float d = x - q;
+                    const double uii = staged ? sm.u[i - a][i - a] : U[(size_t)i * n + i];
+                    const double err = (double)d / uii;
+                    for (int j = i + 1 + l32; j < b; j += 32) {
+                        const double uij = staged ? sm.u[i - a][j - a] : U[(size_t)i * n + j];
+                        const double p = err * uij;
+                        const double v = (double)qref(row, j);
+                        qref(row, j) = (float)(v - p);
+                    }
+                    if (l32 == 0) {
+                        eref(row, i) = (float)err;
+                        qref(row, i) = q;
+                    }
+                }
+            }
+            __syncthreads();
+        } else {
+            // Q[:, b:c] -= E[:, a:b] @ U[a:b, b:c] on the 16 rows of this tile
+            const int a = op.a, b = op.b, c = op.c;
+            const int nblk = (c - b + 15) / 16;
+            const int lr = lane & 15, lk = lane >> 4;
+            for (int blk = wave; blk < nblk; blk += 8) {
+                const int col = b + blk * 16 + lr;
+                const bool col_ok = col < c;
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                for (int k0 = a; k0 < b; k0 += 16) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int k = k0 + 4 * s + lk;
+                        const bool k_ok = k < b;
+                        av[s] = (k_ok && (IN_LDS || r0 + lr < R)) ? (double)eref(lr, k) : 0.0;
+                        bv[s] = (k_ok && col_ok) ? U[(size_t)k * n + col] : 0.0;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+                }
+                if (col_ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = lk + 4 * r;
+                        if (IN_LDS || r0 + row < R) {
+                            const double v = (double)qref(row, col);
+                            qref(row, col) = (float)(v - acc[r]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (IN_LDS) {
+        for (int e = t; e < RB * width; e += 512) {
+            const int r = e / width, c = e % width;
+            if (r0 + r < R) {
+                Qp[(size_t)(r0 + r) * n + w0 + c] = sm.q[r][c];
+                Eg[(size_t)(r0 + r) * n + w0 + c] = sm.e[r][c];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ trailing update
+// Qp[:, ja:jb] = float32(float64(Qp[:, ja:jb]) - E[:, ka:kb] @ U[ka:kb, ja:jb]), 64 x 64 tiles.
+__global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, const float *__restrict__ Eg,
+                                                       const double *__restrict__ U, int R, int n, int ka, int kb,
+                                                       int ja, int jb) {
+    __shared__ Tile64Smem sm;
+    const int r0 = blockIdx.y * TILE, j0 = ja + blockIdx.x * TILE;
+    Acc64 acc;
+    acc.zero();
+    const int kend = ka + (kb - ka + KSTEP - 1) / KSTEP * KSTEP;
+    tile64_mac<true, true>(
+        acc, sm, ka, kend,
+        [&](int r, int k) { return (r0 + r < R && k < kb) ? (double)Eg[(size_t)(r0 + r) * n + k] : 0.0; },
+        [&](int k, int c) { return (k < kb && j0 + c < jb) ? U[(size_t)k * n + j0 + c] : 0.0; });
+    tile64_foreach(acc, [&](int r, int c, double v) {
+        if (r0 + r < R && j0 + c < jb) {
+            float *p = Qp + (size_t)(r0 + r) * n + j0 + c;
+            *p = (float)((double)*p - v);
+        }
+    });
+}
+
+// ------------------------------------------------------------------ host planning
+static void flatten(int a, int b, int mb, int nb, std::vector<Op> &ops) {
+    const int size = b - a;
+    if (size <= mb) {
+        ops.push_back({OP_LEAF, a, b, 0});
+        return;
+    }
+    int step = (size + nb - 1) / nb;
+    if (step < mb) step = mb;
+    for (int s = a; s < b; s += step) {
+        const int e = s + step < b ? s + step : b;
+        flatten(s, e, mb, nb, ops);
+        if (e < b) ops.push_back({OP_UPDATE, s, e, b});
+    }
+}
+
+struct Plan {
+    // kind 0: window [a, b) with ops; kind 1: chip-wide update (a, b, c)
+    struct Step {
+        int kind, a, b, c;
+        std::vector<Op> ops;
+    };
+    std::vector<Step> steps;
+};
+
+static void plan(int a, int b, int mb, int nb, Plan &p) {
+    const int size = b - a;
+    std::vector<Op> ops;
+    flatten(a, b, mb, nb, ops);
+    if (size <= mb || (size <= WMAX && (int)ops.size() <= MAX_OPS)) {
+        p.steps.push_back({0, a, b, 0, ops});
+        return;
+    }
+    int step = (size + nb - 1) / nb;
+    if (step < mb) step = mb;
+    for (int s = a; s < b; s += step) {
+        const int e = s + step < b ? s + step : b;
+        plan(s, e, mb, nb, p);
+        if (e < b) p.steps.push_back({1, s, e, b, {}});
+    }
+}
+
+}  // namespace slk
+
+using namespace slk;
+
+extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long long *order, const double *U,
+                                 int R, int n, int levels, double lo, double hi, int min_block, int num_blocks,
+                                 float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
+                                 slk_stream_t stream) {
+    SLK_REQUIRE(W && U && Q, "null pointer");
+    SLK_REQUIRE(R > 0 && n > 0, "empty layer");
+    SLK_REQUIRE(levels >= 2 && lo < hi, "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(idx == nullptr || levels <= 256, "uint8 indices need levels <= 256");
+    SLK_REQUIRE(min_block >= 1 && num_blocks >= 1, "min_block_size and num_blocks must be >= 1");
+    Arena ws(workspace, ws_bytes);
+    float *Qp = ws.take<float>((size_t)R * n);
+    float *Eg = ws.take<float>((size_t)R * n);
+    int *inv_order = ws.take<int>((size_t)n);
+    if (!Qp || !Eg || !inv_order) {
+        set_error("workspace too small for a %d x %d layer", R, n);
+        return SLK_E_WS;
+    }
+    hipStream_t s = as_stream(stream);
+    const Grid g = make_grid(levels, lo, hi);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gptq_window<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WindowSmem)));
+        attr_set = true;
+    }
+
+    k_permute_in<<<R < 2048 ? R : 2048, 256, 0, s>>>(W, scale, order, R, n, Qp, inv_order);
+    SLK_LAUNCH_CHECK();
+
+    Plan p;
+    plan(0, n, min_block, num_blocks, p);
+    const int row_tiles = (R + RB - 1) / RB;
+    for (const Plan::Step &st : p.steps) {
+        if (st.kind == 0) {
+            const bool in_lds = (st.b - st.a) <= WMAX;
+            // a window's op list may exceed the table only when it is a single wide leaf
+            for (size_t o = 0; o < st.ops.size(); o += MAX_OPS) {
+                OpTable tab;
+                tab.count = (int)(st.ops.size() - o < (size_t)MAX_OPS ? st.ops.size() - o : MAX_OPS);
+                for (int i = 0; i < tab.count; ++i) tab.op[i] = st.ops[o + i];
+                if (in_lds)
+                    k_gptq_window<true><<<row_tiles, 512, sizeof(WindowSmem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g, tab);
+                else
+                    k_gptq_window<false><<<row_tiles, 512, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, g, tab);
+                SLK_LAUNCH_CHECK();
+            }
+        } else {
+            dim3 grid((st.c - st.b + TILE - 1) / TILE, (R + TILE - 1) / TILE);
+            k_gptq_trailing<<<grid, 256, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, st.b, st.c);
+            SLK_LAUNCH_CHECK();
+        }
+    }
+    k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, Q, idx);
+    SLK_LAUNCH_CHECK();
+    if (E_out) SLK_HIP(hipMemcpyAsync(E_out, Eg, sizeof(float) * (size_t)R * n, hipMemcpyDeviceToDevice, s));
+    return SLK_OK;
+}

@@ -1,0 +1,261 @@
+// Hessian preparation ahead of the factorisation (sleekit/obq.py:198-204):
+//   damping with NumPy's float32 diagonal mean, column order, and the gather of
+//   the damped, permuted, index-reversed float64 matrix the factor kernels eat.
+#include "common.h"
+
+namespace slk {
+
+// ------------------------------------------------------------------ diag mean
+// NumPy float32 pairwise summation (oracle/npsum.py states the order):
+//   chunks of 8192; inside a chunk, split at (m/2 rounded down to 8) until the
+//   piece has <= 128 elements; a piece is summed with 8 interleaved accumulators.
+// One workgroup: thread 0 lists the pieces, all threads sum pieces, thread 0
+// folds the piece sums back up the same recursion.
+#define NP_CHUNK 8192
+#define NP_BLOCK 128
+#define NP_MAX_PIECES 128  // 8192 / 64
+
+__device__ float np_piece_sum(const float *a, int m) {
+    if (m < 8) {
+        float r = -0.0f;
+        for (int i = 0; i < m; ++i) r = r + a[i];
+        return r;
+    }
+    float r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < m - (m % 8); i += 8) {
+        r0 = r0 + a[i + 0];
+        r1 = r1 + a[i + 1];
+        r2 = r2 + a[i + 2];
+        r3 = r3 + a[i + 3];
+        r4 = r4 + a[i + 4];
+        r5 = r5 + a[i + 5];
+        r6 = r6 + a[i + 6];
+        r7 = r7 + a[i + 7];
+    }
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < m; ++i) res = res + a[i];
+    return res;
+}
+
+__global__ __launch_bounds__(256) void k_diag_mean(const float *__restrict__ H, int n, int ld,
+                                                   float *__restrict__ out) {
+    __shared__ float vals[NP_CHUNK];
+    __shared__ int piece_lo[NP_MAX_PIECES + 1], piece_len[NP_MAX_PIECES + 1];
+    __shared__ float piece_sum[NP_MAX_PIECES + 1];
+    __shared__ int n_pieces;
+    float total = 0.0f;  // meaningful on thread 0 only
+    for (int base = 0; base < n; base += NP_CHUNK) {
+        const int m = min(NP_CHUNK, n - base);
+        for (int i = threadIdx.x; i < m; i += blockDim.x) vals[i] = H[(size_t)(base + i) * ld + (base + i)];
+        if (threadIdx.x == 0) {
+            // depth-first split, left piece first
+            int stack_lo[16], stack_len[16], sp = 0, k = 0;
+            stack_lo[0] = 0;
+            stack_len[0] = m;
+            sp = 1;
+            while (sp > 0) {
+                --sp;
+                const int lo = stack_lo[sp], len = stack_len[sp];
+                if (len <= NP_BLOCK) {
+                    piece_lo[k] = lo;
+                    piece_len[k] = len;
+                    ++k;
+                } else {
+                    int h = len / 2;
+                    h -= h % 8;
+                    stack_lo[sp] = lo + h;
+                    stack_len[sp] = len - h;
+                    ++sp;
+                    stack_lo[sp] = lo;
+                    stack_len[sp] = h;
+                    ++sp;
+                }
+            }
+            n_pieces = k;
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < n_pieces; p += blockDim.x)
+            piece_sum[p] = np_piece_sum(vals + piece_lo[p], piece_len[p]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // fold: post-order walk of the same recursion with an explicit frame stack
+            int f_len[16], f_stage[16], sp = 0, next = 0;
+            float f_left[16], ret = 0.0f;
+            f_len[0] = m;
+            f_stage[0] = 0;
+            sp = 1;
+            while (sp > 0) {
+                const int t = sp - 1;
+                const int len = f_len[t];
+                if (len <= NP_BLOCK) {
+                    ret = piece_sum[next++];
+                    --sp;
+                    continue;
+                }
+                int h = len / 2;
+                h -= h % 8;
+                if (f_stage[t] == 0) {
+                    f_stage[t] = 1;
+                    f_len[sp] = h;
+                    f_stage[sp] = 0;
+                    ++sp;
+                } else if (f_stage[t] == 1) {
+                    f_left[t] = ret;
+                    f_stage[t] = 2;
+                    f_len[sp] = len - h;
+                    f_stage[sp] = 0;
+                    ++sp;
+                } else {
+                    ret = f_left[t] + ret;
+                    --sp;
+                }
+            }
+            total = total + ret;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = total / (float)n;
+}
+
+// ------------------------------------------------------------------ order keys
+// key[i] = -(double(H_ii) + damp_add) [* double(miss_i)]     (obq.py:64, 69, 81)
+// scal[0] = mean(diag); scal[1] <- damp_add = float32(damp) * mean   (float32 product)
+__global__ __launch_bounds__(256) void k_order_keys(const float *__restrict__ H, int n, float damp,
+                                                    const float *__restrict__ miss, float *scal,
+                                                    double *__restrict__ keys) {
+    const float add = damp * scal[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[1] = add;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double k = -((double)H[(size_t)i * n + i] + (double)add);
+        if (miss) k = k * (double)miss[i];
+        keys[i] = k;
+    }
+}
+
+// Stable argsort by counting: order[rank(i)] = i with rank = #{j : key_j < key_i or (== and j < i)}.
+// n threads, each scanning all keys through LDS tiles (n^2 compares: 17 M at n = 4096).
+// Keys are compared through the usual monotone double -> int64 map, a TOTAL order, so the
+// output is a permutation even for NaN keys (garbage in never becomes an out-of-range index).
+__device__ __forceinline__ long long total_order_key(double k) {
+    long long b = __double_as_longlong(k + 0.0);  // -0.0 -> +0.0: NumPy treats them as a tie
+    return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFLL);
+}
+
+__global__ __launch_bounds__(256) void k_rank_order(const double *__restrict__ keys, int n, int identity,
+                                                    long long *__restrict__ order) {
+    __shared__ long long tile[1024];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (identity) {
+        if (i < n) order[i] = i;
+        return;
+    }
+    const long long ki = i < n ? total_order_key(keys[i]) : 0;
+    int rank = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int m = min(1024, n - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < m; t += blockDim.x) tile[t] = total_order_key(keys[base + t]);
+        __syncthreads();
+        for (int t = 0; t < m; ++t) {
+            const long long kj = tile[t];
+            rank += (kj < ki) || (kj == ki && (base + t) < i);
+        }
+    }
+    if (i < n) order[rank] = i;
+}
+
+// ------------------------------------------------------------------ gather
+// A[i][j] = double(H[p_i][p_j]) + (i == j ? damp_add : 0),  p_i = order[n-1-i],  for i >= j;
+// rows/cols n .. ld-1 are the identity (padding to the factor tile size).
+// The lower triangle of the index-reversed matrix is the triangle LAPACK's
+// potrf('L') reads in the reference (obq.py:47-50), so an asymmetric H gives the same answer.
+__global__ __launch_bounds__(256) void k_gather_reversed(const float *__restrict__ H, int n, int ld,
+                                                         const long long *__restrict__ order,
+                                                         const float *__restrict__ scal,
+                                                         double *__restrict__ A) {
+    const double add = (double)scal[1];
+    for (int i = blockIdx.x; i < ld; i += gridDim.x) {
+        double *row = A + (size_t)i * ld;
+        if (i >= n) {
+            for (int j = threadIdx.x; j < ld; j += blockDim.x) row[j] = (i == j) ? 1.0 : 0.0;
+            continue;
+        }
+        const float *src = H + (size_t)order[n - 1 - i] * n;
+        for (int j = threadIdx.x; j < ld; j += blockDim.x) {
+            double v = 0.0;
+            if (j <= i) {
+                v = (double)src[order[n - 1 - j]];
+                if (j == i) v = v + add;
+            }
+            row[j] = v;
+        }
+    }
+}
+
+// A[i][j] = M[n-1-i][n-1-j] for i >= j (the triangle potrf('L') reads of flip(M)), padded.
+__global__ __launch_bounds__(256) void k_load_reversed(const double *__restrict__ M, int n, int ld,
+                                                       double *__restrict__ A) {
+    for (int i = blockIdx.x; i < ld; i += gridDim.x) {
+        double *row = A + (size_t)i * ld;
+        for (int j = threadIdx.x; j < ld; j += blockDim.x) {
+            double v = 0.0;
+            if (i >= n) v = (i == j) ? 1.0 : 0.0;
+            else if (j <= i) v = M[(size_t)(n - 1 - i) * n + (n - 1 - j)];
+            row[j] = v;
+        }
+    }
+}
+
+}  // namespace slk
+
+using namespace slk;
+
+extern "C" {
+
+int slk_factor_ld(int n) { return (n + 63) / 64 * 64; }
+
+int slk_factor_load(const double *M, int n, double *A, slk_stream_t stream) {
+    SLK_REQUIRE(M && A && n > 0, "bad arguments");
+    const int ld = slk_factor_ld(n);
+    k_load_reversed<<<ld < 2048 ? ld : 2048, 256, 0, as_stream(stream)>>>(M, n, ld, A);
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}
+
+int slk_diag_mean(const float *H, int n, float *out, void *, size_t, slk_stream_t stream) {
+    SLK_REQUIRE(H && out && n > 0, "bad arguments");
+    k_diag_mean<<<1, 256, 0, as_stream(stream)>>>(H, n, n, out);
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}
+
+int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const float *miss,
+                        long long *order_out, double *A, void *workspace, size_t ws_bytes,
+                        slk_stream_t stream) {
+    SLK_REQUIRE(H && order_out && A && n > 0, "bad arguments");
+    SLK_REQUIRE(order_mode >= SLK_ORDER_NONE && order_mode <= SLK_ORDER_SQERR, "Invalid act_order value %d",
+                order_mode);
+    SLK_REQUIRE(order_mode < SLK_ORDER_ERR || miss, "err/sqerr orders need the column statistics");
+    Arena ws(workspace, ws_bytes);
+    float *scal = ws.take<float>(64);
+    double *keys = ws.take<double>((size_t)n);
+    if (!scal || !keys) {
+        set_error("workspace too small");
+        return SLK_E_WS;
+    }
+    hipStream_t s = as_stream(stream);
+    const int ld = slk_factor_ld(n);
+    k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal);
+    SLK_LAUNCH_CHECK();
+    k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, order_mode >= SLK_ORDER_ERR ? miss : nullptr,
+                                                 scal, keys);
+    SLK_LAUNCH_CHECK();
+    k_rank_order<<<(n + 255) / 256, 256, 0, s>>>(keys, n, order_mode == SLK_ORDER_NONE, order_out);
+    SLK_LAUNCH_CHECK();
+    k_gather_reversed<<<ld < 2048 ? ld : 2048, 256, 0, s>>>(H, n, ld, order_out, scal, A);
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}
+
+}  // extern "C"

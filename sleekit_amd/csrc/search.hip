@@ -1,0 +1,218 @@
+// a12 + a13: best-first local search (sleekit/obq.py:220-358).
+//
+// Rows are independent.  One 256-thread workgroup owns one row and keeps the row's state
+// -- W, Q and both gain vectors -- in registers (column j = t + 256 e lives in slot e of
+// thread t), so a move costs one streamed row of H (4n bytes, usually from L2 / Infinity
+// Cache) plus three workgroup reductions:
+//   argmax(gain_up), argmax(gain_down)   first maximum wins, like np.argmax
+//   S = sum_k (Q_old[k] - W[k]) H[c][k]  the interaction term of obq.py:328
+// The candidates Q_up / Q_down of the reference are pure functions of Q (obq.py:257-258,
+// 273-278) and are recomputed instead of stored.  Gains are updated in the reference's
+// order: diagonal term, interaction part 1 (both on the moved column), then part 2 on
+// the whole row (obq.py:322-334), each step rounded to float32.
+//
+// Initial gains (obq.py:231) reuse G = (W - Q) @ H from the error GEMM: delta @ H = -G exactly.
+#include "common.h"
+
+namespace slk {
+
+__device__ __forceinline__ float cand_up(float q, const Grid g) { return grid_val(grid_pos(q, g, 1.0f, 1.0f, g.top), g); }
+__device__ __forceinline__ float cand_down(float q, const Grid g) {
+    return grid_val(grid_pos(q, g, -1.0f, 0.0f, g.top - 1.0f), g);
+}
+
+struct Best {
+    float v;
+    int j;
+};
+__device__ __forceinline__ Best better(Best a, Best b) {
+    // larger value wins; on a tie the smaller column (first occurrence)
+    if (b.v > a.v || (b.v == a.v && b.j < a.j)) return b;
+    return a;
+}
+__device__ __forceinline__ Best wave_best(Best x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        Best o;
+        o.v = __shfl_xor(x.v, m, 64);
+        o.j = __shfl_xor(x.j, m, 64);
+        x = better(x, o);
+    }
+    return x;
+}
+
+__global__ void k_extract_diag(const float *__restrict__ H, int n, float *__restrict__ d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = H[(size_t)i * n + i];
+}
+
+template <int EPT>
+__global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ W, float *__restrict__ Q,
+                                                      const float *__restrict__ H, const float *__restrict__ G,
+                                                      const float *__restrict__ hdiag, int R, int n, Grid g,
+                                                      int moves, uint8_t *__restrict__ idx) {
+    __shared__ Best red_up[4], red_dn[4];
+    __shared__ float red_s[4];
+    const int row = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const size_t base = (size_t)row * n;
+    const float NEG = -__builtin_huge_valf();
+
+    float w[EPT], q[EPT], gu[EPT], gd[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int j = t + 256 * e;
+        if (j < n) {
+            w[e] = W[base + j];
+            q[e] = Q[base + j];
+            const float gj = G[base + j], hjj = hdiag[j];
+            const float du = cand_up(q[e], g) - q[e];
+            const float dd = cand_down(q[e], g) - q[e];
+            // -D^2 * H_jj - 2 * (delta @ H)_j * D  with (delta @ H)_j = -G_j     (obq.py:229-231)
+            gu[e] = (-(du * du)) * hjj + (2.0f * gj) * du;
+            gd[e] = (-(dd * dd)) * hjj + (2.0f * gj) * dd;
+        } else {
+            w[e] = q[e] = 0.0f;
+            gu[e] = gd[e] = NEG;
+        }
+    }
+
+    for (int mv = 0; mv < moves; ++mv) {
+        // ---- best up / best down of the row
+        Best bu = {NEG, 0x7fffffff}, bd = {NEG, 0x7fffffff};
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int j = t + 256 * e;
+            if (gu[e] > bu.v) bu = {gu[e], j};
+            if (gd[e] > bd.v) bd = {gd[e], j};
+        }
+        bu = wave_best(bu);
+        bd = wave_best(bd);
+        __syncthreads();  // previous move's readers of the reduction slots are done
+        if (lane == 0) {
+            red_up[wave] = bu;
+            red_dn[wave] = bd;
+        }
+        __syncthreads();
+        bu = better(better(red_up[0], red_up[1]), better(red_up[2], red_up[3]));
+        bd = better(better(red_dn[0], red_dn[1]), better(red_dn[2], red_dn[3]));
+
+        // ---- decision (obq.py:338-346)
+        const bool go_up = (bu.v > bd.v) && (bu.v > 0.0f);
+        const bool go_down = !go_up && (bd.v > 0.0f);
+        if (!go_up && !go_down) break;  // uniform: nothing can change in later moves either
+        const int c = go_up ? bu.j : bd.j;
+        const int ce = c >> 8, ct = c & 255;  // owner slot / thread of column c
+
+        // ---- stream row c of H: interaction sum with the OLD Q, and part 2 off the moved column
+        const float *hrow = H + (size_t)c * n;
+        float q_old = 0.0f;
+        if (t == ct) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if (e == ce) q_old = q[e];
+        }
+        // broadcast q_old through LDS
+        if (t == ct) red_s[0] = q_old;
+        __syncthreads();
+        q_old = red_s[0];
+        __syncthreads();
+        const float q_new = go_up ? cand_up(q_old, g) : cand_down(q_old, g);
+        const float two_dq = 2.0f * (q_old - q_new);
+
+        float s = 0.0f;
+        float h_cc = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int j = t + 256 * e;
+            if (j < n) {
+                const float h = hrow[j];
+                s = s + (q[e] - w[e]) * h;  // Q still holds the old value at column c
+                if (j == c) {
+                    h_cc = h;
+                } else {
+                    const float f = two_dq * h;
+                    gu[e] = gu[e] + f * (cand_up(q[e], g) - q[e]);
+                    gd[e] = gd[e] + f * (cand_down(q[e], g) - q[e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
+        if (lane == 0) red_s[wave] = s;
+        __syncthreads();
+        s = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+
+        // ---- the moved column: diagonal term, interaction part 1, then part 2 (obq.py:322-334)
+        if (t == ct) {
+            const float d1u = cand_up(q_old, g) - q_old, d2u = cand_up(q_new, g) - q_new;
+            const float d1d = cand_down(q_old, g) - q_old, d2d = cand_down(q_new, g) - q_new;
+            const float hd = hdiag[c];
+            const float f = two_dq * h_cc;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                if (e == ce) {
+                    float x = gu[e];
+                    x = x + hd * (d1u * d1u - d2u * d2u);
+                    x = x + (2.0f * s) * (d1u - d2u);
+                    x = x + f * d2u;
+                    gu[e] = x;
+                    float y = gd[e];
+                    y = y + hd * (d1d * d1d - d2d * d2d);
+                    y = y + (2.0f * s) * (d1d - d2d);
+                    y = y + f * d2d;
+                    gd[e] = y;
+                    q[e] = q_new;
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int j = t + 256 * e;
+        if (j < n) {
+            Q[base + j] = q[e];
+            if (idx) idx[base + j] = (uint8_t)grid_pos(q[e], g, 0.0f, 0.0f, g.top);
+        }
+    }
+}
+
+}  // namespace slk
+
+using namespace slk;
+
+extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
+                                double hi, int moves, uint8_t *idx, void *workspace, size_t ws_bytes,
+                                slk_stream_t stream) {
+    SLK_REQUIRE(W && Q && H && R > 0 && n > 0 && moves >= 0, "bad arguments");
+    SLK_REQUIRE(levels >= 2 && lo < hi, "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(idx == nullptr || levels <= 256, "uint8 indices need levels <= 256");
+    SLK_REQUIRE(n <= 256 * 64, "local search supports n <= 16384");
+    Arena ws(workspace, ws_bytes);
+    float *G = ws.take<float>((size_t)R * n);
+    float *row_err = ws.take<float>((size_t)R);
+    float *hdiag = ws.take<float>((size_t)n);
+    if (!G || !row_err || !hdiag) {
+        set_error("workspace too small");
+        return SLK_E_WS;
+    }
+    const size_t used = align_up(ws.used, 256);
+    int rc = slk_row_errors(W, Q, H, R, n, row_err, G, static_cast<char *>(workspace) + used, ws_bytes - used, stream);
+    if (rc != SLK_OK) return rc;
+    hipStream_t s = as_stream(stream);
+    k_extract_diag<<<(n + 255) / 256, 256, 0, s>>>(H, n, hdiag);
+    SLK_LAUNCH_CHECK();
+    const Grid g = make_grid(levels, lo, hi);
+    const int ept = (n + 255) / 256;
+#define SLK_LS(E) k_local_search<E><<<R, 256, 0, s>>>(W, Q, H, G, hdiag, R, n, g, moves, idx)
+    if (ept <= 4) SLK_LS(4);
+    else if (ept <= 8) SLK_LS(8);
+    else if (ept <= 16) SLK_LS(16);
+    else if (ept <= 32) SLK_LS(32);
+    else if (ept <= 48) SLK_LS(48);
+    else SLK_LS(64);
+#undef SLK_LS
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}

@@ -1,0 +1,144 @@
+// float32 MFMA products on the path:
+//   a11  channelwise_error (sleekit/obq.py:89-95): row_err = rowsum(((W-Q) @ H) * (W-Q))
+//   a1   Sleekit.add_batch (sleekit/statistics.py:76-87): H = H f + X^T X / c'
+// Both are dense contractions on v_mfma_f32_32x32x2_f32 through mfma32.h.
+#include "mfma32.h"
+
+namespace slk {
+
+// ------------------------------------------------------------------ row errors
+// Tile (rows r0.., cols j0..) of G = D @ H with D = W - Q formed on load.  The epilogue
+// multiplies by D again and reduces each row over the tile's 128 columns in a fixed
+// order (lane tree, then the two column waves); partial[r][tile] goes to scratch and a
+// second kernel adds the tiles left to right, so results are run-to-run identical.
+__global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W, const float *__restrict__ Q,
+                                                     const float *__restrict__ H, int R, int n,
+                                                     float *__restrict__ G, float *__restrict__ partial,
+                                                     int n_tiles) {
+    __shared__ Tile128Smem sm;
+    __shared__ float rowpart[2][T32];
+    const int r0 = blockIdx.y * T32, j0 = blockIdx.x * T32;
+    Acc128 acc;
+    acc.zero();
+    const int kend = (n + K32 - 1) / K32 * K32;
+    tile128_mac<true, true>(
+        acc, sm, 0, kend,
+        [&](int r, int k) {
+            const size_t o = (size_t)(r0 + r) * n + k;
+            return (r0 + r < R && k < n) ? W[o] - Q[o] : 0.0f;
+        },
+        [&](int k, int c) { return (k < n && j0 + c < n) ? H[(size_t)k * n + j0 + c] : 0.0f; });
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = j0 + wc * 64 + j * 32 + (lane & 31);
+                const float v = acc.c[i][j][r];
+                if (r0 + row < R && col < n) {
+                    const size_t o = (size_t)(r0 + row) * n + col;
+                    if (G) G[o] = v;
+                    s = s + v * (W[o] - Q[o]);
+                }
+            }
+            // reduce over the 32 lanes that share this row
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
+            if ((lane & 31) == 0) rowpart[wc][row] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < T32 && r0 + threadIdx.x < R)
+        partial[(size_t)(r0 + threadIdx.x) * n_tiles + blockIdx.x] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_error_reduce(const float *__restrict__ partial, int R, int n_tiles,
+                                                      float *__restrict__ row_err) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float s = 0.0f;
+    for (int t = 0; t < n_tiles; ++t) s = s + partial[(size_t)r * n_tiles + t];
+    row_err[r] = s;
+}
+
+// ------------------------------------------------------------------ Hessian accumulation
+// Lower tiles of X^T X, mirrored on store so H stays exactly symmetric.
+__global__ __launch_bounds__(256) void k_hessian_tiles(float *__restrict__ H, const float *__restrict__ X, int n, int T,
+                                                       float factor, float count) {
+    __shared__ Tile128Smem sm;
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    const int i0 = bi * T32, j0 = bj * T32;
+    Acc128 acc;
+    acc.zero();
+    const int kend = (T + K32 - 1) / K32 * K32;
+    tile128_mac<false, true>(
+        acc, sm, 0, kend, [&](int r, int k) { return (i0 + r < n && k < T) ? X[(size_t)k * n + i0 + r] : 0.0f; },
+        [&](int k, int c) { return (k < T && j0 + c < n) ? X[(size_t)k * n + j0 + c] : 0.0f; });
+    tile128_foreach(acc, [&](int r, int c, float v) {
+        const int i = i0 + r, j = j0 + c;
+        if (i < n && j < n && (bi != bj || j <= i)) {
+            const float h = H[(size_t)i * n + j] * factor + v / count;
+            H[(size_t)i * n + j] = h;
+            if (i != j) H[(size_t)j * n + i] = h;
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void k_mean_update(float *__restrict__ mean, const float *__restrict__ X, int n, int T,
+                                                     float factor, float count) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.0f;
+    for (int t = 0; t < T; ++t) s = s + X[(size_t)t * n + j];
+    mean[j] = mean[j] * factor + s / count;
+}
+
+}  // namespace slk
+
+using namespace slk;
+
+extern "C" {
+
+int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n, float *row_err, float *G,
+                   void *workspace, size_t ws_bytes, slk_stream_t stream) {
+    SLK_REQUIRE(W && Q && H && row_err && R > 0 && n > 0, "bad arguments");
+    const int n_tiles = (n + T32 - 1) / T32;
+    Arena ws(workspace, ws_bytes);
+    float *partial = ws.take<float>((size_t)R * n_tiles);
+    if (!partial) {
+        set_error("workspace too small");
+        return SLK_E_WS;
+    }
+    hipStream_t s = as_stream(stream);
+    dim3 grid(n_tiles, (R + T32 - 1) / T32);
+    k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles);
+    SLK_LAUNCH_CHECK();
+    k_error_reduce<<<(R + 255) / 256, 256, 0, s>>>(partial, R, n_tiles, row_err);
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}
+
+int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, long long count_before,
+                           slk_stream_t stream) {
+    SLK_REQUIRE(H && mean && X && n > 0 && T > 0 && count_before >= 0, "bad arguments");
+    const long long after = count_before + T;
+    const float factor = (float)((double)count_before / (double)after);
+    const float count = (float)after;
+    hipStream_t s = as_stream(stream);
+    const int nt = (n + T32 - 1) / T32;
+    k_mean_update<<<(n + 255) / 256, 256, 0, s>>>(mean, X, n, T, factor, count);
+    SLK_LAUNCH_CHECK();
+    dim3 grid(nt, nt);
+    k_hessian_tiles<<<grid, 256, 0, s>>>(H, X, n, T, factor, count);
+    SLK_LAUNCH_CHECK();
+    return SLK_OK;
+}
+
+}  // extern "C"

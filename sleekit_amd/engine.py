@@ -1,0 +1,183 @@
+"""Device-resident pipeline for one layer: the hot path end to end.
+
+    [W / scale] -> column statistics -> damp + order + gather -> factor (float64)
+               -> blocked quantize / propagate loop -> [local search] -> [un-scale]
+
+Every stage is one call into libsleekit_amd.so on the current torch stream; tensors stay
+in HBM and nothing synchronises unless the caller asks for NumPy results.  This is the
+function `sleekit_amd.obq.quantize_opt` and `sleekit_amd.scaling.quantize_with_scaling`
+(the reference's entry points, sleekit/obq.py:169 and sleekit/scaling.py:58) are thin
+wrappers of, and what bench.py times.
+"""
+
+import torch
+
+from . import _device as dev
+from . import _lib
+from .codebook import UniformCodebook
+
+_UNSUPPORTED_ORDERS = ("combined_diag", "inv_diag", "pivot")
+
+
+def order_mode_code(act_order):
+    if act_order in _lib.ORDER_MODES:
+        return _lib.ORDER_MODES[act_order]
+    if act_order in _UNSUPPORTED_ORDERS:
+        raise NotImplementedError(
+            f"act_order={act_order!r} needs a dense inverse / pivoted Cholesky and is outside the accelerated path"
+        )
+    raise RuntimeError(f"Invalid act_order value {act_order}")
+
+
+def require_uniform(quantizer):
+    if not isinstance(quantizer, UniformCodebook):
+        raise NotImplementedError(
+            "sleekit_amd runs UniformCodebook quantizers on the GPU and has no CPU fallback for arbitrary "
+            f"callables (got {type(quantizer).__name__})"
+        )
+    if len(quantizer) > 256:
+        raise NotImplementedError("codebooks above 256 entries are not on the accelerated path")
+    return quantizer._abi()
+
+
+class LayerResult:
+    """Device tensors produced for one layer."""
+
+    __slots__ = ("Q", "idx", "order", "U", "info", "E")
+
+    def __init__(self):
+        self.Q = self.idx = self.order = self.U = self.info = self.E = None
+
+
+def factorize(H, n, damp, mode, miss=None, keep=None):
+    """Damping + order + float64 factor for a float32 device Hessian. Returns (order, U, info)."""
+    ws, ws_bytes = dev.workspace(0, n)
+    s = dev.stream_handle()
+    ld = _lib.lib.slk_factor_ld(n)
+    order = torch.empty(n, dtype=torch.int64, device=H.device)
+    A = torch.empty(ld * ld, dtype=torch.float64, device=H.device)
+    U = torch.empty((n, n), dtype=torch.float64, device=H.device)
+    info = torch.empty(1, dtype=torch.int32, device=H.device)
+    _lib.check(
+        _lib.lib.slk_hessian_prepare(
+            dev.ptr(H), n, float(damp), mode, dev.ptr(miss), dev.ptr(order), dev.ptr(A), dev.ptr(ws), ws_bytes, s
+        )
+    )
+    _lib.check(_lib.lib.slk_chol_inverse_upper(dev.ptr(A), n, dev.ptr(U), dev.ptr(info), dev.ptr(ws), ws_bytes, s))
+    return order, U, info
+
+
+def factorize_order_only(H, n, mode, miss=None):
+    """Column order of an already damped float32 Hessian (compute_hessian_order, obq.py:58-86)."""
+    ws, ws_bytes = dev.workspace(0, n)
+    ld = _lib.lib.slk_factor_ld(n)
+    order = torch.empty(n, dtype=torch.int64, device=H.device)
+    A = torch.empty(ld * ld, dtype=torch.float64, device=H.device)
+    _lib.check(
+        _lib.lib.slk_hessian_prepare(
+            dev.ptr(H), n, 0.0, mode, dev.ptr(miss), dev.ptr(order), dev.ptr(A), dev.ptr(ws), ws_bytes,
+            dev.stream_handle(),
+        )
+    )
+    return order, None, None
+
+
+def run_loop(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=True, want_E=False):
+    """The column-sequential loop on device tensors. Returns (Q, idx, E)."""
+    R, n = W.shape
+    levels, lo, hi = cb_abi
+    ws, ws_bytes = dev.workspace(R, n)
+    Q = torch.empty((R, n), dtype=torch.float32, device=W.device)
+    idx = torch.empty((R, n), dtype=torch.uint8, device=W.device) if want_idx else None
+    E = torch.empty((R, n), dtype=torch.float32, device=W.device) if want_E else None
+    _lib.check(
+        _lib.lib.slk_gptq_quantize(
+            dev.ptr(W), dev.ptr(scale), dev.ptr(order), dev.ptr(U), R, n, levels, lo, hi, int(min_block),
+            int(num_blocks), dev.ptr(Q), dev.ptr(idx), dev.ptr(E), dev.ptr(ws), ws_bytes, dev.stream_handle(),
+        )
+    )
+    return Q, idx, E
+
+
+def local_search(W, Q, H, cb_abi, moves, idx=None):
+    """In place on Q (and idx)."""
+    R, n = W.shape
+    levels, lo, hi = cb_abi
+    ws, ws_bytes = dev.workspace(R, n)
+    _lib.check(
+        _lib.lib.slk_local_search(
+            dev.ptr(W), dev.ptr(Q), dev.ptr(H), R, n, levels, lo, hi, int(moves), dev.ptr(idx), dev.ptr(ws),
+            ws_bytes, dev.stream_handle(),
+        )
+    )
+
+
+def rows_divide(x, scale, invert=False):
+    R, n = x.shape
+    out = torch.empty_like(x)
+    _lib.check(
+        _lib.lib.slk_rows_divide(dev.ptr(x), dev.ptr(scale), R, n, 1 if invert else 0, dev.ptr(out), dev.stream_handle())
+    )
+    return out
+
+
+def column_miss(W, cb_abi, squared):
+    R, n = W.shape
+    levels, lo, hi = cb_abi
+    out = torch.empty(n, dtype=torch.float32, device=W.device)
+    _lib.check(
+        _lib.lib.slk_column_miss(dev.ptr(W), R, n, levels, lo, hi, 1 if squared else 0, dev.ptr(out), dev.stream_handle())
+    )
+    return out
+
+
+def row_errors(W, Q, H, want_G=False):
+    R, n = W.shape
+    ws, ws_bytes = dev.workspace(R, n)
+    out = torch.empty(R, dtype=torch.float32, device=W.device)
+    G = torch.empty((R, n), dtype=torch.float32, device=W.device) if want_G else None
+    _lib.check(
+        _lib.lib.slk_row_errors(
+            dev.ptr(W), dev.ptr(Q), dev.ptr(H), R, n, dev.ptr(out), dev.ptr(G), dev.ptr(ws), ws_bytes, dev.stream_handle()
+        )
+    )
+    return (out, G) if want_G else out
+
+
+def quantize_layer(
+    W, H, quantizer, scale=None, act_order="diag", damp=0.01, nb_ls_moves=0, min_block_size=32, num_blocks=8,
+    factor=None, unscale=True, want_idx=True,
+):
+    """One layer through the whole path, on device tensors.
+
+    W (R, n) float32, H (n, n) float32, scale (R,) float32 or None.  `factor` = (order, U, info)
+    re-uses a factor computed elsewhere (another GPU: see sleekit_amd.dist).  Returns a
+    LayerResult whose Q is de-scaled when `scale` is given and `unscale` is true
+    (sleekit/scaling.py:58-81), else the codebook values in the scaled domain
+    (sleekit/obq.py:169-217).
+    """
+    assert W.ndim == 2
+    assert H.ndim == 2
+    assert H.shape[0] == H.shape[1]
+    assert H.shape[0] == W.shape[1]
+    assert min_block_size >= 1
+    cb_abi = require_uniform(quantizer)
+    mode = order_mode_code(act_order)
+    R, n = W.shape
+    res = LayerResult()
+
+    need_scaled_copy = scale is not None and (mode >= _lib.ORDER_ERR or nb_ls_moves > 0)
+    Ws, loop_scale = (rows_divide(W, scale), None) if need_scaled_copy else (W, scale)
+
+    if factor is None:
+        miss = column_miss(Ws, cb_abi, mode == _lib.ORDER_SQERR) if mode >= _lib.ORDER_ERR else None
+        factor = factorize(H, n, damp, mode, miss)
+        dev.note_info(factor[2], "compute_hessian_chol")
+    res.order, res.U, res.info = factor
+
+    res.Q, res.idx, _ = run_loop(Ws, loop_scale, res.order, res.U, cb_abi, min_block_size, num_blocks, want_idx)
+    if nb_ls_moves > 0:
+        local_search(Ws, res.Q, H, cb_abi, nb_ls_moves, res.idx)
+    if scale is not None and unscale:
+        res.Q = rows_divide(res.Q, scale, invert=True)
+    return res

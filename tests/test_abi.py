@@ -1,0 +1,105 @@
+"""CPU checks of the drop-in boundary: the library loads and exports what the header declares."""
+
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "sleekit_amd.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(slk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sleekit_amd import _lib
+
+    names = declared_symbols()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(_lib.lib, name), f"{name} declared in the header but not exported"
+    assert sorted(_lib.PROTOTYPES) == names, "ctypes prototypes and header out of step"
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r" T (slk_[a-z0-9_]+)", out)))
+    assert exported == names
+
+
+def test_abi_version_and_sizes():
+    from sleekit_amd import _lib
+
+    assert _lib.lib.slk_abi_version() == 1
+    assert _lib.lib.slk_factor_ld(1) == 64 and _lib.lib.slk_factor_ld(64) == 64 and _lib.lib.slk_factor_ld(11008) == 11008
+    assert _lib.lib.slk_factor_ld(1100) == 1152
+    # 4096 x 4096: two float64 n x n scratch matrices dominate
+    assert _lib.lib.slk_workspace_bytes(4096, 4096) >= 2 * 4096 * 4096 * 8
+    assert _lib.lib.slk_workspace_bytes(512, 11008) >= 2 * 11008 * 11008 * 8
+
+
+def test_argument_errors_do_not_touch_the_gpu():
+    """Bad arguments are rejected on the host before any launch (safe without a GPU)."""
+    from sleekit_amd import _lib
+
+    assert _lib.lib.slk_codebook_apply(None, 4, 1, -1.0, 1.0, 0, None, None) == _lib.E_ARG
+    assert b"levels" in _lib.lib.slk_last_error()
+    assert _lib.lib.slk_gptq_quantize(None, None, None, None, 4, 4, 8, -1.0, 1.0, 32, 8, None, None, None, None, 0, None) == _lib.E_ARG
+    assert _lib.lib.slk_hessian_prepare(None, 0, 0.01, 1, None, None, None, None, 0, None) == _lib.E_ARG
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.E_ARG)
+
+
+def test_product_has_no_cpu_path():
+    """Without a GPU the product raises instead of computing on the host; it never imports the oracle."""
+    import sys
+
+    import numpy as np
+    import torch
+
+    from sleekit_amd import codebook, obq, scaling
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cb = codebook.UniformCodebook(8, -1, 1)
+    W = np.zeros((4, 8), np.float32)
+    H = np.eye(8, dtype=np.float32)
+    for call in (
+        lambda: cb(W),
+        lambda: obq.quantize_opt(W, H, cb),
+        lambda: scaling.quantize_with_scaling(W, np.ones(4, np.float32), cb, H),
+        lambda: obq.quantization_error(W, W, H),
+    ):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()
+    for mod in ("sleekit_amd.obq", "sleekit_amd.engine", "sleekit_amd.scaling", "sleekit_amd.codebook"):
+        src = open(sys.modules[mod].__file__).read()
+        assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_interface_mirrors_reference_names():
+    from sleekit_amd import codebook, obq, scaling
+    import sleekit_amd
+
+    for name in ("remove_input_bias", "remove_dead_values", "compute_hessian_chol", "compute_hessian_order",
+                 "channelwise_error", "quantization_error", "_quantize_opt_core", "_quantize_opt_block",
+                 "quantize_opt", "compute_gain", "LocalSearchQuantizer", "quantize_local_search", "random_psd_matrix", "np"):
+        assert hasattr(obq, name), name
+    for name in ("apply_scaling", "apply_scaling_in_place", "compute_norm_scaling", "compute_non_saturating_scaling",
+                 "quantize_with_scaling", "compute_min_mse_scaling", "compute_obq_scaling", "compute_scaling", "np"):
+        assert hasattr(scaling, name), name
+    for name in ("UniformCodebook", "Codebook", "lloyd_max", "np"):
+        assert hasattr(codebook, name), name
+    assert sleekit_amd.Sleekit is not None
+    cb = codebook.UniformCodebook(8, -1, 1)
+    assert len(cb) == 8 and cb.min() == -1 and cb.max() == 1 and cb.zero == -1 and abs(cb.scale - 2 / 7) < 1e-15
+    import inspect
+
+    sig = inspect.signature(obq.quantize_opt)
+    assert [p for p in sig.parameters] == ["W", "H", "quantizer", "act_order", "damp", "nb_ls_moves", "min_block_size", "num_blocks"]
+    assert sig.parameters["damp"].default == 0.01 and sig.parameters["min_block_size"].default == 32
+    sig = inspect.signature(scaling.quantize_with_scaling)
+    assert [p for p in sig.parameters] == ["data", "scale", "quantizer", "H", "act_order", "damp", "nb_ls_moves"]

@@ -1,0 +1,299 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+Integer/index results are compared bit-for-bit; float64 factors to 1e-9 relative (they
+need not match LAPACK bit-wise: SURVEY.md 8a6); layer errors to 1e-5 relative (north_star).
+"""
+
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import parse_case
+from oracle import grid, npsum, obq_ref, scaling_ref, stats_ref
+from sleekit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+_layers = {}
+
+
+def layer(R, n, seed, **kw):
+    key = (R, n, seed, tuple(sorted(kw.items())))
+    if key not in _layers:
+        _layers[key] = synth.make_layer(R, n, seed, **kw)
+    return _layers[key]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def amd():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from sleekit_amd import _lib, codebook, engine, obq, scaling, statistics
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.lib, ns.codebook, ns.engine, ns.obq, ns.scaling, ns.statistics = _lib, codebook, engine, obq, scaling, statistics
+    return ns
+
+
+def run_product(amd, L, c):
+    cb = amd.codebook.UniformCodebook(c["levels"], -1, 1)
+    H = amd.obq.remove_input_bias(L["H"], L["mean"]) if c["strip"] else L["H"]
+    out = amd.scaling.quantize_with_scaling(L["W"], L["scale"], cb, H, c["order"], c["damp"], c["moves"])
+    idx = cb.quantize_index(amd.scaling.apply_scaling(out, L["scale"], 0))
+    return out, idx, amd.obq.channelwise_error(L["W"], out, H), amd.obq.quantization_error(L["W"], out, H)
+
+
+# --------------------------------------------------------------------------- element-wise stages
+@pytest.mark.parametrize("levels", [2, 3, 4, 8, 16, 256, "asym"])
+def test_codebook_maps_bit_exact(amd, pieces, levels):
+    x = pieces["cb/x"]
+    cb = amd.codebook.UniformCodebook(5, -0.75, 1.25) if levels == "asym" else amd.codebook.UniformCodebook(levels, -1, 1)
+    tag = "cb/asym" if levels == "asym" else f"cb/N{levels}"
+    for name in ("value", "index", "up", "down"):
+        got = getattr(cb, "quantize_" + name)(x)
+        want = pieces[f"{tag}/{name}"]
+        assert got.dtype == want.dtype and np.array_equal(got, want), (levels, name)
+
+
+def test_float32_divide_is_ieee(amd):
+    """apply_scaling must be a correctly rounded divide, incl. subnormal results (scaling.py:21-25, 80)."""
+    rng = np.random.default_rng(3)
+    W = (rng.standard_normal((257, 1031)) * np.exp(rng.uniform(-30, 30, (257, 1031)))).astype(np.float32)
+    W[0, :8] = [0.0, -0.0, 1e-38, -1e-38, 1e-45, 3.4e38, 1.0, -1.0]
+    sc = np.exp(rng.uniform(-20, 20, 257)).astype(np.float32)
+    got = amd.scaling.apply_scaling(W, sc, 0)
+    assert np.array_equal(got, scaling_ref.divide_rows(W, sc, 0))
+    back = amd.engine.rows_divide(torch.from_numpy(got).cuda(), torch.from_numpy(sc).cuda(), invert=True).cpu().numpy()
+    assert np.array_equal(back, scaling_ref.divide_rows(got, 1 / sc, 0))
+
+
+def test_scale_helpers_and_rtn(amd, pieces):
+    L = layer(64, 96, 2001)
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    assert np.array_equal(amd.scaling.apply_scaling(L["W"], L["scale"], 0), pieces["scale/apply"])
+    assert np.array_equal(amd.scaling.quantize_with_scaling(L["W"], L["scale"], cb), pieces["scale/rtn"])
+    W2 = L["W"].copy()
+    amd.scaling.apply_scaling_in_place(W2, L["scale"], 0)
+    assert np.array_equal(W2, pieces["scale/apply"])
+
+
+def test_dead_columns_and_mean_removal(amd, pieces):
+    L = layer(32, 64, 2020, dead=(3, 17, 40))
+    H, W = L["H"].copy(), L["W"].copy()
+    amd.obq.remove_dead_values(H, W)
+    assert np.array_equal(H, pieces["dead/H"]) and np.array_equal(W, pieces["dead/W"])
+    assert np.array_equal(amd.obq.remove_input_bias(L["H"], L["mean"]), pieces["strip/H"])
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    out = amd.scaling.quantize_with_scaling(W, L["scale"], cb, H)
+    assert np.array_equal(cb.quantize_index(amd.scaling.apply_scaling(out, L["scale"], 0)), pieces["dead/idx"])
+    np.testing.assert_allclose(amd.obq.quantization_error(W, out, H), pieces["dead/err"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 127, 128, 129, 768, 1100, 4096, 8192, 8200, 11008])
+def test_diag_mean_follows_numpy_order(amd, n):
+    rng = np.random.default_rng(n)
+    d = (np.square(rng.standard_normal(n)) * 3).astype(np.float32)
+    H = torch.zeros((n, n), dtype=torch.float32, device="cuda")
+    H.diagonal().copy_(torch.from_numpy(d))
+    out = torch.empty(1, dtype=torch.float32, device="cuda")
+    amd.lib.check(amd.lib.lib.slk_diag_mean(H.data_ptr(), n, out.data_ptr(), None, 0, None))
+    assert np.float32(out.item()) == npsum.mean_f32(d) == d.mean()
+
+
+# --------------------------------------------------------------------------- order + factor
+@pytest.mark.parametrize("R,n,seed", [(8, 16, 2000), (64, 96, 2001), (96, 172, 2003), (256, 768, 2010), (8, 1100, 2040)])
+def test_order_and_factor(amd, R, n, seed):
+    L = layer(R, n, seed)
+    H = L["H"]
+    Hd = H + 0.01 * H.diagonal().mean() * np.eye(n)
+    want_order = obq_ref.column_order(L["W"], Hd, None, "diag")
+    order, U, info = amd.engine.factorize(torch.from_numpy(H).cuda(), n, 0.01, amd.lib.ORDER_DIAG)
+    assert int(info.item()) == 0
+    assert np.array_equal(order.cpu().numpy(), want_order)
+    want_U = obq_ref.inverse_factor_upper(Hd[want_order][:, want_order])
+    got_U = U.cpu().numpy()
+    assert np.array_equal(got_U, np.triu(got_U))
+    scale = np.abs(want_U).max()
+    assert np.abs(got_U - np.triu(want_U)).max() <= 1e-9 * scale
+    # defining property, independent of LAPACK: U^T U = Hd[order][:, order]^-1
+    P = Hd[want_order][:, want_order]
+    assert np.abs(got_U.T @ got_U @ P - np.eye(n)).max() < 1e-8
+
+
+def test_factor_of_plain_matrix_and_not_pd(amd):
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((200, 150))
+    M = A.T @ A + 0.5 * np.eye(150)  # asymmetric-looking input is fine: only one triangle is read
+    U = amd.obq.compute_hessian_chol(M)
+    want = obq_ref.inverse_factor_upper(M)
+    assert np.abs(U - np.triu(want)).max() <= 1e-10 * np.abs(want).max()
+    M[70, 70] = -1.0
+    with pytest.raises(np.linalg.LinAlgError):
+        amd.obq.compute_hessian_chol(M)
+    with pytest.raises(np.linalg.LinAlgError):
+        obq_ref.inverse_factor_upper(M)
+
+
+def test_orders_err_sqerr(amd):
+    L = layer(64, 96, 2001)
+    g = grid.UniformGrid(8, -1, 1)
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    Ws = scaling_ref.divide_rows(L["W"], L["scale"], 0)
+    for mode, squared in (("err", False), ("sqerr", True)):
+        miss = amd.engine.column_miss(torch.from_numpy(Ws).cuda(), cb._abi(), squared).cpu().numpy()
+        d = g(Ws) - Ws
+        want = (np.square(d) if squared else np.abs(d)).sum(axis=0)
+        assert np.array_equal(miss, want), mode
+
+
+# --------------------------------------------------------------------------- the loop
+def test_loop_trace_bit_exact(amd, pieces):
+    """Q and E after the blocked loop with the reference's own factor: isolates the loop kernels."""
+    L = layer(8, 16, 2000)
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    order = pieces["trace/order"]
+    Ws = scaling_ref.divide_rows(L["W"], L["scale"], 0)
+    Q = Ws[:, order].copy()
+    E = np.zeros_like(Q)
+    amd.obq._quantize_opt_block(Q, E, pieces["trace/U"], cb, 4, 2)
+    assert np.array_equal(Q, pieces["trace/Q"])
+    assert np.array_equal(E, pieces["trace/E"])
+
+
+@pytest.mark.parametrize("min_block,num_blocks", [(1, 2), (3, 2), (4, 4), (7, 2), (8, 4), (63, 2), (64, 4), (32, 8), (1000, 8)])
+def test_loop_blockings_match_oracle(amd, min_block, num_blocks):
+    """Every recursion shape the reference's own test sweeps (tests/test_obq.py:57-70), bit for bit."""
+    L = layer(96, 172, 2003)
+    g = grid.UniformGrid(8, -1, 1)
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    Ws = scaling_ref.divide_rows(L["W"], L["scale"], 0)
+    Hd = L["H"] + 0.01 * L["H"].diagonal().mean() * np.eye(172)
+    U = obq_ref.inverse_factor_upper(Hd)
+    Q0, E0 = Ws.copy(), np.zeros_like(Ws)
+    obq_ref.run_schedule(Q0, E0, U, g, obq_ref.block_schedule(172, min_block, num_blocks))
+    Q1, E1 = Ws.copy(), np.zeros_like(Ws)
+    amd.obq._quantize_opt_block(Q1, E1, U, cb, min_block, num_blocks)
+    assert np.array_equal(Q1, Q0)
+    np.testing.assert_allclose(E1, E0, rtol=1e-6, atol=1e-7)
+
+
+def test_small_cases_bit_exact(amd, small_cases):
+    names = [str(x) for x in small_cases["names"]]
+    bad = []
+    for name in names:
+        c = parse_case(name)
+        L = layer(c["R"], c["n"], c["seed"])
+        out, idx, rows, err = run_product(amd, L, c)
+        if not np.array_equal(idx, small_cases[name + "/idx"]):
+            bad.append((name, int((idx != small_cases[name + "/idx"]).sum())))
+            continue
+        want = float(small_cases[name + "/err"])
+        assert abs(float(err) - want) <= 1e-5 * abs(want), (name, float(err), want)
+        np.testing.assert_allclose(rows, small_cases[name + "/row_err"], rtol=2e-4, atol=1e-7, err_msg=name)
+    assert not bad, bad
+
+
+def test_quantize_opt_direct_and_device_tensors(amd):
+    """quantize_opt on already scaled weights; device tensors in -> device tensors out, same bits."""
+    L = layer(128, 256, 2002)
+    g = grid.UniformGrid(4, -1, 1)
+    cb = amd.codebook.UniformCodebook(4, -1, 1)
+    Ws = scaling_ref.divide_rows(L["W"], L["scale"], 0)
+    want = obq_ref.quantize_layer(Ws, L["H"], g, "diag", 0.01, 0)
+    got = amd.obq.quantize_opt(Ws, L["H"], cb)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    got_dev = amd.obq.quantize_opt(torch.from_numpy(Ws).cuda(), torch.from_numpy(L["H"]).cuda(), cb)
+    assert got_dev.is_cuda and np.array_equal(got_dev.cpu().numpy(), want)
+    with pytest.raises(RuntimeError):
+        amd.obq.quantize_opt(Ws, L["H"], cb, act_order="bogus")
+    with pytest.raises(AssertionError):
+        amd.obq.quantize_opt(Ws, L["H"][:-1], cb)
+    with pytest.raises(NotImplementedError):
+        amd.obq.quantize_opt(Ws, L["H"], lambda x: np.round(x))
+
+
+def test_local_search_standalone(amd):
+    L = layer(64, 96, 2001)
+    g = grid.UniformGrid(8, -1, 1)
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    Ws = scaling_ref.divide_rows(L["W"], L["scale"], 0)
+    Q0 = g(Ws)
+    for moves in (1, 3, 25):
+        want = obq_ref.local_search(Ws, Q0, L["H"], g, moves)
+        got = amd.obq.quantize_local_search(Ws, Q0, L["H"], cb, moves)
+        assert np.array_equal(got, want), moves
+    assert amd.obq.quantize_local_search(Ws, Q0, L["H"], cb, 0) is Q0
+    np.testing.assert_allclose(amd.obq.compute_gain(Ws, Q0, L["H"], g.up(Q0)), obq_ref.flip_gains(Ws, Q0, L["H"], g.up(Q0)),
+                               rtol=1e-4, atol=1e-5)
+
+
+def test_hessian_accumulate(amd, pieces):
+    X = pieces["stats/X"]
+    lin = torch.nn.Linear(48, 10).cuda()
+    st = amd.statistics.Sleekit(lin)
+    for a, b in ((0, 64), (64, 72), (72, 200)):
+        st.add_batch(torch.from_numpy(X[a:b]).reshape(1, b - a, 48).cuda())
+    assert st.count == int(pieces["stats/count"])
+    np.testing.assert_allclose(st.hessian.cpu().numpy(), pieces["stats/H"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st.mean.cpu().numpy(), pieces["stats/mean"], rtol=1e-5, atol=1e-7)
+    H = st.hessian.cpu().numpy()
+    assert np.array_equal(H, H.T)
+    # a larger, ragged shape against the float64 truth
+    n, T = 300, 1000
+    Xb = synth.make_activations(T, n, 77).astype(np.float32)
+    st = amd.statistics.Sleekit(torch.nn.Linear(n, 4).cuda())
+    st.add_batch(torch.from_numpy(Xb[:333]).cuda())
+    st.add_batch(torch.from_numpy(Xb[333:]).cuda())
+    truth = Xb.astype(np.float64).T @ Xb.astype(np.float64) / T
+    np.testing.assert_allclose(st.hessian.cpu().numpy(), truth, rtol=1e-5, atol=1e-5 * np.abs(truth).max())
+
+
+# --------------------------------------------------------------------------- BASELINE-sized layers
+def _large(amd, c):
+    L = layer(c["R"], c["n"], c["seed"])
+    assert sha(L["W"]) == c["sha_W"] and sha(L["H"]) == c["sha_H"] and sha(L["scale"]) == c["sha_scale"]
+    out, idx, rows, err = run_product(amd, L, dict(levels=c["levels"], order=c["order"], damp=c["damp"],
+                                                   moves=c["moves"], strip=c["strip_mean"]))
+    mism = int((np.bincount(idx.ravel(), minlength=c["levels"]) != np.array(c["idx_histogram"])).sum())
+    assert sha(idx) == c["sha_idx"], f"indices differ from the reference (histogram bins off: {mism})"
+    assert abs(float(err) - c["err"]) <= 1e-5 * abs(c["err"]), (float(err), c["err"])
+
+
+@pytest.mark.parametrize("shape", ["768x768", "3072x768", "768x3072", "1024x1024", "1024x4096", "4096x1024", "4096x4096"])
+def test_large_cases_against_reference_hashes(amd, large_cases, shape):
+    todo = [c for c in large_cases if f"{c['R']}x{c['n']}" == shape]
+    assert todo
+    for c in todo:
+        _large(amd, c)
+
+
+def test_headline_properties_4096(amd):
+    """Size-independent properties at the headline size: blocking is a pure re-association,
+    row shards are independent, indices decode to the returned values."""
+    L = layer(4096, 4096, 1007)
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    W, H, sc = (torch.from_numpy(L[k]).cuda() for k in ("W", "H", "scale"))
+    full = amd.engine.quantize_layer(W, H, cb, sc)
+    # (1) a row shard with the same factor gives the same rows
+    part = amd.engine.quantize_layer(W[1024:1536].contiguous(), H, cb, sc[1024:1536].contiguous(),
+                                     factor=(full.order, full.U, full.info))
+    assert torch.equal(part.idx, full.idx[1024:1536]) and torch.equal(part.Q, full.Q[1024:1536])
+    # (2) indices decode to the scaled-domain values
+    scaled = amd.engine.quantize_layer(W, H, cb, sc, unscale=False, factor=(full.order, full.U, full.info))
+    vals = torch.linspace(-1, 1, 8, device="cuda", dtype=torch.float64)[full.idx.long()].float()
+    assert torch.allclose(scaled.Q, vals, rtol=0, atol=1e-6)
+    # (3) a different blocking changes no index (tests/test_obq.py:57-70 at full size)
+    other = amd.engine.quantize_layer(W, H, cb, sc, min_block_size=32, num_blocks=4, factor=(full.order, full.U, full.info))
+    assert (other.idx != full.idx).sum().item() == 0
+    # (4) GPTQ beats round-to-nearest
+    rtn = amd.scaling.quantize_with_scaling(W, sc, cb)
+    assert float(amd.obq.quantization_error(W, full.Q, H)) < float(amd.obq.quantization_error(W, rtn, H))

@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mweights/s quantized (GPTQ 3-bit, 4096 x 4096 layers) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One STEP = one pass of the hot path over a batch of `--layers` (default 8) synthetic
+4096 x 4096 layers, 3-bit uniform codebook, act_order="diag", damp=0.01, no local search
+(BASELINE.json's headline metric): per layer
+    scale -> damp + order + gather -> float64 factor -> blocked quantize/propagate loop -> un-scale
+    -> layer error (W - Qw) H (W - Qw)^T
+with W, H and the row scales resident in HBM before the clock starts.  N > 1 shards the
+rows of every layer across the ranks (sleekit_amd/dist.py); the factor of layer l is made by
+rank l mod N and broadcast once over RCCL.  Total work is the same at every N ("strong").
+
+The JSON line also carries
+  roofline      for the kernel with the largest share of the step (timed with HIP events
+                 around every launch, on the launch stream: slk_profile_* in the C ABI),
+                 achieved = ALGORITHMIC flops or bytes of its launches / their summed duration;
+  cpu_baseline  the NumPy oracle (bit-identical to the reference, tests/test_oracle_golden.py)
+                 timed on this host for one 4096 x 4096 layer, rank 0, N = 1 only.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md; float64 from the CDNA4 datasheet:
+# vector = matrix = 78.6 TFLOP/s, i.e. 32 flop/clk/SIMD at 2.4 GHz on 1024 SIMDs)
+PEAK = {"hbm": (8.0e12, "GB/s"), "mfma_f64": (78.6e12, "TFLOP/s"), "mfma_f32": (157.3e12, "TFLOP/s")}
+KERNEL_DTYPE = {
+    "chol_panel": "mfma_f64", "chol_syrk": "mfma_f64", "trtri_stage0": "mfma_f64", "trtri_stage1": "mfma_f64",
+    "gptq_window": "mfma_f64", "gptq_window_wide": "mfma_f64", "gptq_trailing": "mfma_f64",
+    "error_gemm": "mfma_f32", "hessian_syrk": "mfma_f32",
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=8, help="layers per step")
+    ap.add_argument("--rows", type=int, default=4096)
+    ap.add_argument("--cols", type=int, default=4096)
+    ap.add_argument("--levels", type=int, default=8, help="codebook size (8 = 3 bit)")
+    ap.add_argument("--moves", type=int, default=0, help="local-search moves")
+    ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic layers cycled through the batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="also print per-kernel timing table to stderr")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from sleekit_amd import _device as dev
+    from sleekit_amd import _lib, codebook, synth
+    from sleekit_amd import dist as sdist
+
+    dev.lazy_errors = True
+    R, n, L = args.rows, args.cols, args.layers
+    cb = codebook.UniformCodebook(args.levels, -1, 1)
+
+    # ---- inputs, resident in HBM (identical on every rank: integer-hash generator)
+    t_setup = time.time()
+    base = []
+    for i in range(min(args.distinct, L)):
+        lay = synth.make_layer(R, n, 1000 + i, device=device)
+        base.append({k: torch.from_numpy(lay[k]).to(device) for k in ("W", "H", "scale")})
+    layers = [base[i % len(base)] for i in range(L)]
+    host_layer0 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        host_layer0 = {k: base[0][k].cpu().numpy() for k in ("W", "H", "scale")}
+    t_setup = time.time() - t_setup
+
+    backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True)
+
+    def step():
+        shards = sdist.quantize_stream(layers, backend)
+        return shards
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        shards = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    dev.raise_pending()
+    ms_per_step = 1e3 * elapsed / args.steps
+    weights_per_step = float(L) * R * n
+    value = weights_per_step / (elapsed / args.steps) / 1e6
+
+    # layer error of the last step (sanity: finite, GPTQ-sized) -- bookkeeping, not timed
+    err0 = float(sdist.layer_error(shards[0]["row_err"], R).item())
+
+    # ---- per-kernel timing of one more step with HIP events around every launch
+    roofline, table = None, []
+    if not args.no_profile:
+        fence()
+        _lib.lib.slk_profile_reset()
+        _lib.lib.slk_profile_enable(1)
+        step()
+        torch.cuda.synchronize()
+        _lib.lib.slk_profile_enable(0)
+        table = _lib.profile_report()
+        _lib.lib.slk_profile_reset()
+        fence()
+        if table:
+            top = max(table, key=lambda k: k["total_ms"])
+            secs = top["total_ms"] * 1e-3
+            kind = KERNEL_DTYPE.get(top["kernel"])
+            t_flops = top["flops"] / PEAK[kind][0] if kind else 0.0
+            t_bytes = top["bytes"] / PEAK["hbm"][0]
+            if kind and t_flops >= t_bytes:
+                achieved, peak, unit, bound = top["flops"] / secs / 1e12, PEAK[kind][0] / 1e12, "TFLOP/s", "mfma"
+            else:
+                achieved, peak, unit, bound = top["bytes"] / secs / 1e9, PEAK["hbm"][0] / 1e9, "GB/s", "hbm"
+            roofline = {
+                "kernel": top["kernel"], "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "launches_per_step": top["launches"], "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
+                "share_of_step": round(top["total_ms"] / sum(k["total_ms"] for k in table), 3),
+                "peak_kind": kind or "hbm",
+            }
+        if args.stages and rank == 0:
+            tot = sum(k["total_ms"] for k in table)
+            for k in sorted(table, key=lambda k: -k["total_ms"]):
+                print(
+                    f"  {k['kernel']:<20s} {k['launches']:5d} launches {k['total_ms']:9.3f} ms {100 * k['total_ms'] / tot:5.1f}%"
+                    f"  {k['flops'] / max(k['total_ms'], 1e-9) / 1e9:9.2f} TFLOP/s {k['bytes'] / max(k['total_ms'], 1e-9) / 1e6:9.1f} GB/s",
+                    file=sys.stderr,
+                )
+
+    # ---- CPU baseline: the oracle on the host cores, one layer of the same workload
+    cpu = None
+    if host_layer0 is not None:
+        from oracle import grid, obq_ref, scaling_ref
+
+        g = grid.UniformGrid(args.levels, -1, 1)
+        small = synth.make_layer(512, 512, 999)
+        scaling_ref.quantize_scaled(small["W"], small["scale"], g, small["H"])  # LAPACK/BLAS warm-up
+        t1 = time.perf_counter()
+        out = scaling_ref.quantize_scaled(host_layer0["W"], host_layer0["scale"], g, host_layer0["H"], "diag", 0.01, args.moves)
+        e_cpu = float(obq_ref.mean_error(host_layer0["W"], out, host_layer0["H"]))
+        t_cpu = time.perf_counter() - t1
+        cpu = {
+            "value": round(R * n / t_cpu / 1e6, 3), "unit": "Mweights/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 layer {R}x{n} (same inputs as GPU layer 0), quantize_with_scaling + quantization_error, "
+                      f"NumPy {np.__version__} OpenBLAS threads=all, after a 512x512 warm-up; {t_cpu:.2f} s",
+            "layer_error": e_cpu, "gpu_layer_error": err0,
+        }
+
+    if rank == 0:
+        line = {
+            "metric": "Mweights/sec quantized (GPTQ 3-bit, 4096x4096 layer)", "value": round(value, 2), "unit": "Mweights/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{L} layers {R}x{n}, {args.levels}-level uniform codebook (GPTQ {np.log2(args.levels):g}-bit), "
+                            f"act_order=diag, damp=0.01, local-search moves={args.moves}, layer error included",
+                "layers_per_step": L, "rows": R, "cols": n, "row_sharding": f"{world} ranks x {R // world} rows",
+                "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(t_setup, 1),
+            },
+            "roofline": roofline, "cpu_baseline": cpu, "layer_error": err0,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,15 @@ int slk_diag_mean(const float *H, int n, float *out, void *workspace, size_t ws_
 int slk_probe_mfma_f64(double *sink, int blocks, int iters, slk_stream_t stream);
 int slk_probe_mfma_f32(float *sink, int blocks, int iters, slk_stream_t stream);
 
+/* Per-launch timing (off by default).  While enabled, every kernel launch is bracketed by
+ * HIP events on its own stream.  slk_profile_report synchronises on them and writes a JSON
+ * array with, per kernel name, the launch count, total milliseconds and the ALGORITHMIC
+ * flops / bytes of those launches (the roofline numerators of DESIGN.md); it returns the
+ * length needed, like snprintf.  Do not enable while capturing a hipGraph.          */
+int slk_profile_enable(int on);
+int slk_profile_reset(void);
+int slk_profile_report(char *buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,18 +63,27 @@ def inverse_factor_upper(H):
     return np.ascontiguousarray(np.flip(R))
 
 
-def column_order(W, H, grid, mode):
-    """Column processing order (obq.py:58-86), restricted to the hot-path modes."""
+def column_order(W, H, grid, mode, ties="numpy"):
+    """Column processing order (obq.py:58-86), restricted to the hot-path modes.
+
+    `ties`: the reference calls `argsort()` with NumPy's default UNSTABLE sort, so the
+    order of columns whose keys are exactly equal is whatever that sort leaves (it depends
+    on the NumPy build's SIMD dispatch).  "numpy" reproduces the reference call as is;
+    "stable" breaks exact ties by column index, which is what the device kernel does.
+    The two differ only when two keys are bit-identical (it happens: float32 diagonals of
+    a 4096-column Hessian collide now and then).
+    """
+    kind = {"numpy": None, "stable": "stable"}[ties]
     if mode == "diag":
-        return (-H.diagonal()).argsort()
+        return (-H.diagonal()).argsort(kind=kind)
     if mode == "none":
         return np.arange(W.shape[1])
     if mode == "err":
         miss = np.abs(grid(W) - W).sum(axis=0)
-        return (-H.diagonal() * miss).argsort()
+        return (-H.diagonal() * miss).argsort(kind=kind)
     if mode == "sqerr":
         miss = np.square(grid(W) - W).sum(axis=0)
-        return (-H.diagonal() * miss).argsort()
+        return (-H.diagonal() * miss).argsort(kind=kind)
     raise RuntimeError(f"Invalid act_order value {mode}")
 
 
@@ -141,7 +150,7 @@ def run_schedule(Q, E, U, grid, ops):
 
 
 def quantize_layer(
-    W, H, grid, order_mode="diag", damp=0.01, ls_moves=0, min_block=32, num_blocks=8
+    W, H, grid, order_mode="diag", damp=0.01, ls_moves=0, min_block=32, num_blocks=8, ties="numpy"
 ):
     """GPTQ-style quantization of one layer (obq.py:169-217). Returns grid values, float32."""
     assert W.ndim == 2 and H.ndim == 2
@@ -152,7 +161,7 @@ def quantize_layer(
     n = H.shape[0]
 
     H_damped = H + damp * H.diagonal().mean() * np.eye(n)
-    order = column_order(W, H_damped, grid, order_mode)
+    order = column_order(W, H_damped, grid, order_mode, ties)
 
     Wp = W[:, order]
     Q = Wp.copy()

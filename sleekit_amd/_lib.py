@@ -51,7 +51,20 @@ PROTOTYPES = {
     "slk_diag_mean": (c_int, [P, c_int, P, P, c_size_t, P]),
     "slk_probe_mfma_f64": (c_int, [P, c_int, c_int, P]),
     "slk_probe_mfma_f32": (c_int, [P, c_int, c_int, P]),
+    "slk_profile_enable": (c_int, [c_int]),
+    "slk_profile_reset": (c_int, []),
+    "slk_profile_report": (c_int, [c_char_p, c_size_t]),
 }
+
+
+def profile_report():
+    """Parsed slk_profile_report(): list of dicts per kernel name."""
+    import json
+
+    need = lib.slk_profile_report(None, 0)
+    buf = ctypes.create_string_buffer(need + 1)
+    lib.slk_profile_report(buf, need + 1)
+    return json.loads(buf.value.decode())
 
 for _name, (_res, _args) in PROTOTYPES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of step

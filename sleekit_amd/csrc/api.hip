@@ -56,16 +56,122 @@ size_t slk_workspace_bytes(int R, int n) {
 
 int slk_probe_mfma_f64(double *sink, int blocks, int iters, slk_stream_t stream) {
     SLK_REQUIRE(sink && blocks > 0 && iters > 0, "bad arguments");
-    k_probe_f64<<<blocks, 256, 0, as_stream(stream)>>>(sink, iters);
-    SLK_LAUNCH_CHECK();
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("probe_mfma_f64", 4.0 * 2048 * 4 * iters * blocks, 0, s, k_probe_f64<<<blocks, 256, 0, s>>>(sink, iters));
     return SLK_OK;
 }
 
 int slk_probe_mfma_f32(float *sink, int blocks, int iters, slk_stream_t stream) {
     SLK_REQUIRE(sink && blocks > 0 && iters > 0, "bad arguments");
-    k_probe_f32<<<blocks, 256, 0, as_stream(stream)>>>(sink, iters);
-    SLK_LAUNCH_CHECK();
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("probe_mfma_f32", 4.0 * 4096 * 4 * iters * blocks, 0, s, k_probe_f32<<<blocks, 256, 0, s>>>(sink, iters));
     return SLK_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ per-launch profiler
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace slk {
+namespace {
+struct ProfEntry {
+    const char *name;
+    double flops, bytes;
+    hipEvent_t start, stop;
+};
+struct ProfState {
+    bool on = false;
+    std::vector<ProfEntry> entries;
+    std::vector<hipEvent_t> pool;
+    std::mutex mu;
+} g_prof;
+
+hipEvent_t prof_event() {
+    if (!g_prof.pool.empty()) {
+        hipEvent_t e = g_prof.pool.back();
+        g_prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+ProfScope::ProfScope(const char *name, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    ProfEntry e{name, flops, bytes, prof_event(), prof_event()};
+    if (!e.start || !e.stop) return;
+    (void)hipEventRecord(e.start, s);
+    g_prof.entries.push_back(e);
+    slot = (int)g_prof.entries.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    (void)hipEventRecord(g_prof.entries[slot].stop, stream);
+}
+}  // namespace slk
+
+extern "C" {
+
+int slk_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    g_prof.on = on != 0;
+    return SLK_OK;
+}
+
+int slk_profile_reset(void) {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    for (auto &e : g_prof.entries) {
+        g_prof.pool.push_back(e.start);
+        g_prof.pool.push_back(e.stop);
+    }
+    g_prof.entries.clear();
+    return SLK_OK;
+}
+
+// Waits for the recorded launches and writes a JSON array, one object per kernel name:
+//   {"kernel": ..., "launches": n, "total_ms": t, "flops": sum, "bytes": sum}
+// Returns the number of characters needed (like snprintf).
+int slk_profile_report(char *buf, size_t cap) {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    struct Agg {
+        long n = 0;
+        double ms = 0, flops = 0, bytes = 0;
+    };
+    std::map<std::string, Agg> agg;
+    std::vector<std::string> order;
+    for (auto &e : g_prof.entries) {
+        if (hipEventSynchronize(e.stop) != hipSuccess) continue;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.start, e.stop) != hipSuccess) continue;
+        if (!agg.count(e.name)) order.push_back(e.name);
+        Agg &a = agg[e.name];
+        a.n += 1;
+        a.ms += ms;
+        a.flops += e.flops;
+        a.bytes += e.bytes;
+    }
+    std::string out = "[";
+    char line[512];
+    for (size_t i = 0; i < order.size(); ++i) {
+        const Agg &a = agg[order[i]];
+        snprintf(line, sizeof(line), "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 i ? ", " : "", order[i].c_str(), a.n, a.ms, a.flops, a.bytes);
+        out += line;
+    }
+    out += "]";
+    if (buf && cap > 0) {
+        snprintf(buf, cap, "%s", out.c_str());
+    }
+    return (int)out.size();
 }
 
 }  // extern "C"

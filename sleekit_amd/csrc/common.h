@@ -31,6 +31,26 @@ void set_error(const char *fmt, ...);
 
 #define SLK_LAUNCH_CHECK() SLK_HIP(hipGetLastError())
 
+// Optional per-launch timing (slk_profile_*): when enabled every kernel launch is bracketed
+// by a pair of HIP events on its own stream, tagged with its name and ALGORITHMIC flops and
+// bytes (the roofline numerators of DESIGN.md).  Disabled: one predictable branch.
+struct ProfScope {
+    int slot;
+    hipStream_t stream;
+    ProfScope(const char *name, double flops, double bytes, hipStream_t s);
+    ~ProfScope();
+};
+
+// SLK_RUN("kernel name", flops, bytes, stream, kernel<<<grid, block, smem, stream>>>(args...));
+#define SLK_RUN(name, flops, bytes, stream, ...)                 \
+    do {                                                         \
+        {                                                        \
+            slk::ProfScope prof_scope_(name, flops, bytes, stream); \
+            __VA_ARGS__;                                         \
+        }                                                        \
+        SLK_LAUNCH_CHECK();                                      \
+    } while (0)
+
 static inline hipStream_t as_stream(slk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -126,13 +126,13 @@ int slk_codebook_apply(const float *x, size_t count, int levels, double lo, doub
     const Grid g = make_grid(levels, lo, hi);
     const int blocks = stream_blocks(count, 256 * 4);
     hipStream_t s = as_stream(stream);
+    const double bytes = (double)count * (what == SLK_CB_INDEX ? 5.0 : 8.0);
     switch (what) {
-        case SLK_CB_VALUE: k_codebook<SLK_CB_VALUE><<<blocks, 256, 0, s>>>(x, count, g, out); break;
-        case SLK_CB_INDEX: k_codebook<SLK_CB_INDEX><<<blocks, 256, 0, s>>>(x, count, g, out); break;
-        case SLK_CB_UP: k_codebook<SLK_CB_UP><<<blocks, 256, 0, s>>>(x, count, g, out); break;
-        default: k_codebook<SLK_CB_DOWN><<<blocks, 256, 0, s>>>(x, count, g, out); break;
+        case SLK_CB_VALUE: SLK_RUN("codebook_apply", 0, bytes, s, k_codebook<SLK_CB_VALUE><<<blocks, 256, 0, s>>>(x, count, g, out)); break;
+        case SLK_CB_INDEX: SLK_RUN("codebook_apply", 0, bytes, s, k_codebook<SLK_CB_INDEX><<<blocks, 256, 0, s>>>(x, count, g, out)); break;
+        case SLK_CB_UP: SLK_RUN("codebook_apply", 0, bytes, s, k_codebook<SLK_CB_UP><<<blocks, 256, 0, s>>>(x, count, g, out)); break;
+        default: SLK_RUN("codebook_apply", 0, bytes, s, k_codebook<SLK_CB_DOWN><<<blocks, 256, 0, s>>>(x, count, g, out)); break;
     }
-    SLK_LAUNCH_CHECK();
     return SLK_OK;
 }
 
@@ -141,8 +141,8 @@ int slk_rows_divide(const float *x, const float *scale, int R, int n, int invert
     SLK_REQUIRE(R >= 0 && n >= 0, "negative shape");
     if (R == 0 || n == 0) return SLK_OK;
     SLK_REQUIRE(x && scale && out, "null pointer");
-    k_rows_divide<<<stream_blocks(R, 1), 256, 0, as_stream(stream)>>>(x, scale, R, n, invert, out);
-    SLK_LAUNCH_CHECK();
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("rows_divide", 0, 8.0 * R * n, s, k_rows_divide<<<stream_blocks(R, 1), 256, 0, s>>>(x, scale, R, n, invert, out));
     return SLK_OK;
 }
 
@@ -150,8 +150,8 @@ int slk_hessian_strip_mean(const float *H, const float *mean, int n, float *out,
     SLK_REQUIRE(n >= 0, "negative shape");
     if (n == 0) return SLK_OK;
     SLK_REQUIRE(H && mean && out, "null pointer");
-    k_strip_mean<<<stream_blocks(n, 1), 256, 0, as_stream(stream)>>>(H, mean, n, out);
-    SLK_LAUNCH_CHECK();
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("hessian_strip_mean", 0, 8.0 * n * n, s, k_strip_mean<<<stream_blocks(n, 1), 256, 0, s>>>(H, mean, n, out));
     return SLK_OK;
 }
 
@@ -169,12 +169,9 @@ int slk_hessian_patch_dead(float *H, float *W, int R, int n, void *workspace, si
     int rc = slk_diag_mean(H, n, fill, static_cast<char *>(workspace) + align_up(used, 256),
                            ws_bytes - align_up(used, 256), stream);
     if (rc != SLK_OK) return rc;
-    k_patch_dead<<<stream_blocks(n, 256), 256, 0, as_stream(stream)>>>(H, W, R, n, fill, dead);
-    SLK_LAUNCH_CHECK();
-    if (W && R > 0) {
-        k_zero_dead<<<stream_blocks(R, 1), 256, 0, as_stream(stream)>>>(W, R, n, dead);
-        SLK_LAUNCH_CHECK();
-    }
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("patch_dead", 0, 8.0 * n, s, k_patch_dead<<<stream_blocks(n, 256), 256, 0, s>>>(H, W, R, n, fill, dead));
+    if (W && R > 0) SLK_RUN("zero_dead", 0, 1.0 * n, s, k_zero_dead<<<stream_blocks(R, 1), 256, 0, s>>>(W, R, n, dead));
     return SLK_OK;
 }
 
@@ -182,9 +179,9 @@ int slk_column_miss(const float *W, int R, int n, int levels, double lo, double 
                     float *miss, slk_stream_t stream) {
     SLK_REQUIRE(levels >= 2 && lo < hi, "codebook needs levels >= 2 and lo < hi");
     SLK_REQUIRE(R >= 0 && n > 0 && W && miss, "bad arguments");
-    k_column_miss<<<(n + 255) / 256, 256, 0, as_stream(stream)>>>(W, R, n, make_grid(levels, lo, hi),
-                                                                  squared, miss);
-    SLK_LAUNCH_CHECK();
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("column_miss", 0, 4.0 * R * n, s,
+            k_column_miss<<<(n + 255) / 256, 256, 0, s>>>(W, R, n, make_grid(levels, lo, hi), squared, miss));
     return SLK_OK;
 }
 

@@ -180,37 +180,49 @@ extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, vo
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelSmem)));
         attr_set = true;
     }
-    k_clear_info<<<1, 1, 0, s>>>(info);
+    SLK_RUN("clear_info", 0, 4, s, k_clear_info<<<1, 1, 0, s>>>(info));
 
     for (int K0 = 0; K0 < ld; K0 += OUTER) {
         const int K1 = K0 + OUTER < ld ? K0 + OUTER : ld;
         for (int k0 = K0; k0 < K1; k0 += PANEL) {
             const int below = (ld - k0) / PANEL;  // tiles from the diagonal tile down
-            k_chol_panel<<<below, 256, sizeof(PanelSmem), s>>>(A, ld, k0, X, info);
-            SLK_LAUNCH_CHECK();
+            // potf2 + inverse of the 64-tile (2/3 * 64^3) and the triangular product below it
+            SLK_RUN("chol_panel", 2.0 / 3.0 * 64 * 64 * 64 + (double)(below - 1) * 64 * 64 * 64, 16.0 * below * 64 * 64, s,
+                    k_chol_panel<<<below, 256, sizeof(PanelSmem), s>>>(A, ld, k0, X, info));
             // inner update: columns of this outer block to the right of the panel
             const int tj0 = k0 / TILE + 1, tj1 = K1 / TILE;
             if (tj1 > tj0) {
                 dim3 grid(tj1 - tj0, nt - tj0);
-                k_syrk_tiles<<<grid, 256, 0, s>>>(A, ld, tj0, tj0, k0, k0 + PANEL);
-                SLK_LAUNCH_CHECK();
+                double tiles = 0;
+                for (int bj = tj0; bj < tj1; ++bj) tiles += nt - bj;
+                SLK_RUN("chol_syrk", tiles * 2.0 * 64 * 64 * PANEL, 8.0 * (ld - k0) * PANEL + tiles * 16.0 * 64 * 64, s,
+                        k_syrk_tiles<<<grid, 256, 0, s>>>(A, ld, tj0, tj0, k0, k0 + PANEL));
             }
         }
         const int t0 = K1 / TILE;
         if (nt > t0) {
             dim3 grid(nt - t0, nt - t0);
-            k_syrk_tiles<<<grid, 256, 0, s>>>(A, ld, t0, t0, K0, K1);
-            SLK_LAUNCH_CHECK();
+            const double tiles = 0.5 * (nt - t0) * (nt - t0 + 1);
+            SLK_RUN("chol_syrk", tiles * 2.0 * 64 * 64 * (K1 - K0), 8.0 * (ld - K1) * (K1 - K0) + tiles * 16.0 * 64 * 64, s,
+                    k_syrk_tiles<<<grid, 256, 0, s>>>(A, ld, t0, t0, K0, K1));
         }
     }
     for (int lvl = 1; lvl < nt; lvl *= 2) {
         dim3 grid(nt, nt);
-        k_trtri_level<0><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl);
-        SLK_LAUNCH_CHECK();
-        k_trtri_level<1><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl);
-        SLK_LAUNCH_CHECK();
+        // work of this level: for every node, tiles (bi in B, bj in A) with their triangular K ranges
+        double f0 = 0, f1 = 0, tiles = 0;
+        for (int lo = 0; lo + lvl < nt; lo += 2 * lvl) {
+            const int mid = lo + lvl, hi = lo + 2 * lvl < nt ? lo + 2 * lvl : nt;
+            for (int bi = mid; bi < hi; ++bi)
+                for (int bj = lo; bj < mid; ++bj) {
+                    f0 += 2.0 * 64 * 64 * 64 * (mid - bj);
+                    f1 += 2.0 * 64 * 64 * 64 * (bi + 1 - mid);
+                    tiles += 1;
+                }
+        }
+        SLK_RUN("trtri_stage0", f0, f0 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64, s, k_trtri_level<0><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
+        SLK_RUN("trtri_stage1", f1, f1 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64, s, k_trtri_level<1><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
     }
-    k_flip_out<<<n < 2048 ? n : 2048, 256, 0, s>>>(X, ld, n, U);
-    SLK_LAUNCH_CHECK();
+    SLK_RUN("flip_out", 0, 12.0 * n * n, s, k_flip_out<<<n < 2048 ? n : 2048, 256, 0, s>>>(X, ld, n, U));
     return SLK_OK;
 }

@@ -276,8 +276,7 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
         attr_set = true;
     }
 
-    k_permute_in<<<R < 2048 ? R : 2048, 256, 0, s>>>(W, scale, order, R, n, Qp, inv_order);
-    SLK_LAUNCH_CHECK();
+    SLK_RUN("permute_in", 0, 8.0 * R * n, s, k_permute_in<<<R < 2048 ? R : 2048, 256, 0, s>>>(W, scale, order, R, n, Qp, inv_order));
 
     Plan p;
     plan(0, n, min_block, num_blocks, p);
@@ -289,21 +288,34 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
             for (size_t o = 0; o < st.ops.size(); o += MAX_OPS) {
                 OpTable tab;
                 tab.count = (int)(st.ops.size() - o < (size_t)MAX_OPS ? st.ops.size() - o : MAX_OPS);
-                for (int i = 0; i < tab.count; ++i) tab.op[i] = st.ops[o + i];
+                double fl = 0, ub = 0;  // float64 flops per row; bytes of U the window touches
+                for (int i = 0; i < tab.count; ++i) {
+                    const Op &q = tab.op[i] = st.ops[o + i];
+                    if (q.kind == OP_LEAF) {
+                        const double w = q.b - q.a;
+                        fl += w * (w - 1);
+                        ub += 4.0 * w * (w + 1);
+                    } else {
+                        fl += 2.0 * (q.b - q.a) * (q.c - q.b);
+                        ub += 8.0 * (q.b - q.a) * (q.c - q.b);
+                    }
+                }
+                const double wbytes = 12.0 * R * (st.b - st.a) + ub;  // Q in/out + E out, U once
                 if (in_lds)
-                    k_gptq_window<true><<<row_tiles, 512, sizeof(WindowSmem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g, tab);
+                    SLK_RUN("gptq_window", fl * R, wbytes, s,
+                            k_gptq_window<true><<<row_tiles, 512, sizeof(WindowSmem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g, tab));
                 else
-                    k_gptq_window<false><<<row_tiles, 512, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, g, tab);
-                SLK_LAUNCH_CHECK();
+                    SLK_RUN("gptq_window_wide", fl * R, wbytes, s,
+                            k_gptq_window<false><<<row_tiles, 512, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, g, tab));
             }
         } else {
             dim3 grid((st.c - st.b + TILE - 1) / TILE, (R + TILE - 1) / TILE);
-            k_gptq_trailing<<<grid, 256, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, st.b, st.c);
-            SLK_LAUNCH_CHECK();
+            const double K = st.b - st.a, N = st.c - st.b;
+            SLK_RUN("gptq_trailing", 2.0 * R * K * N, 4.0 * R * K + 8.0 * K * N + 8.0 * R * N, s,
+                    k_gptq_trailing<<<grid, 256, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, st.b, st.c));
         }
     }
-    k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, Q, idx);
-    SLK_LAUNCH_CHECK();
+    SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, Q, idx));
     if (E_out) SLK_HIP(hipMemcpyAsync(E_out, Eg, sizeof(float) * (size_t)R * n, hipMemcpyDeviceToDevice, s));
     return SLK_OK;
 }

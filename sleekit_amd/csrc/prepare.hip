@@ -218,15 +218,15 @@ int slk_factor_ld(int n) { return (n + 63) / 64 * 64; }
 int slk_factor_load(const double *M, int n, double *A, slk_stream_t stream) {
     SLK_REQUIRE(M && A && n > 0, "bad arguments");
     const int ld = slk_factor_ld(n);
-    k_load_reversed<<<ld < 2048 ? ld : 2048, 256, 0, as_stream(stream)>>>(M, n, ld, A);
-    SLK_LAUNCH_CHECK();
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("factor_load", 0, 4.0 * n * n + 8.0 * ld * ld, s, k_load_reversed<<<ld < 2048 ? ld : 2048, 256, 0, s>>>(M, n, ld, A));
     return SLK_OK;
 }
 
 int slk_diag_mean(const float *H, int n, float *out, void *, size_t, slk_stream_t stream) {
     SLK_REQUIRE(H && out && n > 0, "bad arguments");
-    k_diag_mean<<<1, 256, 0, as_stream(stream)>>>(H, n, n, out);
-    SLK_LAUNCH_CHECK();
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("diag_mean", 0, 4.0 * n, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, out));
     return SLK_OK;
 }
 
@@ -246,15 +246,12 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
     }
     hipStream_t s = as_stream(stream);
     const int ld = slk_factor_ld(n);
-    k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal);
-    SLK_LAUNCH_CHECK();
-    k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, order_mode >= SLK_ORDER_ERR ? miss : nullptr,
-                                                 scal, keys);
-    SLK_LAUNCH_CHECK();
-    k_rank_order<<<(n + 255) / 256, 256, 0, s>>>(keys, n, order_mode == SLK_ORDER_NONE, order_out);
-    SLK_LAUNCH_CHECK();
-    k_gather_reversed<<<ld < 2048 ? ld : 2048, 256, 0, s>>>(H, n, ld, order_out, scal, A);
-    SLK_LAUNCH_CHECK();
+    SLK_RUN("diag_mean", 0, 4.0 * n, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
+    SLK_RUN("order_keys", 0, 12.0 * n, s,
+            k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, order_mode >= SLK_ORDER_ERR ? miss : nullptr, scal, keys));
+    SLK_RUN("rank_order", 0, 16.0 * n, s, k_rank_order<<<(n + 255) / 256, 256, 0, s>>>(keys, n, order_mode == SLK_ORDER_NONE, order_out));
+    SLK_RUN("gather_reversed", 0, 2.0 * n * n + 8.0 * ld * ld, s,
+            k_gather_reversed<<<ld < 2048 ? ld : 2048, 256, 0, s>>>(H, n, ld, order_out, scal, A));
     return SLK_OK;
 }
 

@@ -201,11 +201,12 @@ extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R,
     int rc = slk_row_errors(W, Q, H, R, n, row_err, G, static_cast<char *>(workspace) + used, ws_bytes - used, stream);
     if (rc != SLK_OK) return rc;
     hipStream_t s = as_stream(stream);
-    k_extract_diag<<<(n + 255) / 256, 256, 0, s>>>(H, n, hdiag);
-    SLK_LAUNCH_CHECK();
+    SLK_RUN("extract_diag", 0, 8.0 * n, s, k_extract_diag<<<(n + 255) / 256, 256, 0, s>>>(H, n, hdiag));
     const Grid g = make_grid(levels, lo, hi);
     const int ept = (n + 255) / 256;
-#define SLK_LS(E) k_local_search<E><<<R, 256, 0, s>>>(W, Q, H, G, hdiag, R, n, g, moves, idx)
+#define SLK_LS(E)                                                                                     \
+    SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,             \
+            k_local_search<E><<<R, 256, 0, s>>>(W, Q, H, G, hdiag, R, n, g, moves, idx))
     if (ept <= 4) SLK_LS(4);
     else if (ept <= 8) SLK_LS(8);
     else if (ept <= 16) SLK_LS(16);
@@ -213,6 +214,5 @@ extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R,
     else if (ept <= 48) SLK_LS(48);
     else SLK_LS(64);
 #undef SLK_LS
-    SLK_LAUNCH_CHECK();
     return SLK_OK;
 }

@@ -118,10 +118,9 @@ int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n,
     }
     hipStream_t s = as_stream(stream);
     dim3 grid(n_tiles, (R + T32 - 1) / T32);
-    k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles);
-    SLK_LAUNCH_CHECK();
-    k_error_reduce<<<(R + 255) / 256, 256, 0, s>>>(partial, R, n_tiles, row_err);
-    SLK_LAUNCH_CHECK();
+    SLK_RUN("error_gemm", 2.0 * R * n * n, 8.0 * R * n + 4.0 * n * n + (G ? 4.0 * R * n : 0.0), s,
+            k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles));
+    SLK_RUN("error_reduce", 0, 4.0 * R * n_tiles, s, k_error_reduce<<<(R + 255) / 256, 256, 0, s>>>(partial, R, n_tiles, row_err));
     return SLK_OK;
 }
 
@@ -133,11 +132,10 @@ int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, 
     const float count = (float)after;
     hipStream_t s = as_stream(stream);
     const int nt = (n + T32 - 1) / T32;
-    k_mean_update<<<(n + 255) / 256, 256, 0, s>>>(mean, X, n, T, factor, count);
-    SLK_LAUNCH_CHECK();
+    SLK_RUN("mean_update", 0, 4.0 * T * n, s, k_mean_update<<<(n + 255) / 256, 256, 0, s>>>(mean, X, n, T, factor, count));
     dim3 grid(nt, nt);
-    k_hessian_tiles<<<grid, 256, 0, s>>>(H, X, n, T, factor, count);
-    SLK_LAUNCH_CHECK();
+    SLK_RUN("hessian_syrk", (double)T * n * (n + 1), 4.0 * T * n + 8.0 * n * n, s,
+            k_hessian_tiles<<<grid, 256, 0, s>>>(H, X, n, T, factor, count));
     return SLK_OK;
 }
 

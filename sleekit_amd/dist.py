@@ -1,0 +1,119 @@
+"""Row-sharded quantization of a stream of layers over the GPUs of one node.
+
+Given the shared factor U, every output row of W goes through the loop, the local search
+and the error on its own (sleekit/obq.py:106-137, 264-346, 89-95 have no cross-row term),
+so the path shards by rows with no data-path collective.  What does NOT shard is the
+n x n factorisation; over a stream of layers it is spread instead: rank (l mod G) factors
+layer l and broadcasts (order, U, status) once -- one RCCL broadcast per layer over xGMI --
+while every rank runs rows [r R/G, (r+1) R/G) of every layer.
+
+One process per GPU; `torch.distributed` must be initialised by the caller (backend "nccl"
+is RCCL on ROCm).  The broadcasts are issued asynchronously up front, so layer l's loop
+overlaps the transfer of layer l+1's factor; on a single rank nothing is communicated.
+
+The module is engine-agnostic: `backend` supplies factorize / run_rows, which lets the CPU
+test-suite drive the same scheduling code over gloo with a stand-in backend.
+"""
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def row_range(R, rank, size):
+    """Rows [lo, hi) of rank `rank`: contiguous, sizes differ by at most one, covers [0, R) exactly."""
+    base, extra = divmod(R, size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def factor_root(layer_index, size):
+    return layer_index % size
+
+
+class HipBackend:
+    """The real thing: sleekit_amd.engine on the current device."""
+
+    def __init__(self, quantizer, act_order="diag", damp=0.01, nb_ls_moves=0, with_error=True):
+        from . import engine
+
+        self.engine, self.quantizer = engine, quantizer
+        self.act_order, self.damp, self.moves, self.with_error = act_order, damp, nb_ls_moves, with_error
+
+    def alloc_factor(self, n, device):
+        return (
+            torch.empty(n, dtype=torch.int64, device=device),
+            torch.empty((n, n), dtype=torch.float64, device=device),
+            torch.empty(1, dtype=torch.int32, device=device),
+        )
+
+    def factorize(self, layer):
+        eng = self.engine
+        W, H, n = layer["W"], layer["H"], layer["H"].shape[0]
+        mode = eng.order_mode_code(self.act_order)
+        miss = None
+        if mode >= 2:  # err / sqerr need the statistics of ALL rows, before sharding
+            cb = eng.require_uniform(self.quantizer)
+            Ws = eng.rows_divide(W, layer["scale"]) if layer.get("scale") is not None else W
+            miss = eng.column_miss(Ws, cb, mode == 3)
+        return eng.factorize(H, n, self.damp, mode, miss)
+
+    def run_rows(self, layer, lo, hi, factor):
+        eng = self.engine
+        W = layer["W"][lo:hi].contiguous()
+        sc = layer["scale"][lo:hi].contiguous() if layer.get("scale") is not None else None
+        res = eng.quantize_layer(W, layer["H"], self.quantizer, sc, self.act_order, self.damp, self.moves, factor=factor)
+        err = eng.row_errors(W, res.Q, layer["H"]) if self.with_error else None
+        return dict(Q=res.Q, idx=res.idx, row_err=err, rows=(lo, hi))
+
+
+def quantize_stream(layers, backend, comm_device=None):
+    """Quantize `layers` (list of dicts with W (R, n), H (n, n), optional scale (R,)) across the ranks.
+
+    Returns, per layer, this rank's shard: dict(Q, idx, row_err, rows=(lo, hi), info).
+    Every rank holds every layer's inputs (W, H are inputs of the path and resident before
+    it starts); only the factor travels.
+    """
+    rank, size = world()
+    n_layers = len(layers)
+    factors = [None] * n_layers
+    # 1. every rank factors the layers it is the root of (concurrently across ranks)
+    for l in range(rank, n_layers, size):
+        factors[l] = backend.factorize(layers[l])
+    # 2. one asynchronous broadcast per layer from its root, issued in layer order
+    pending = [None] * n_layers
+    if size > 1:
+        for l in range(n_layers):
+            root = factor_root(l, size)
+            if root != rank:
+                dev = comm_device if comm_device is not None else layers[l]["H"].device
+                factors[l] = backend.alloc_factor(layers[l]["H"].shape[0], dev)
+            pending[l] = [dist.broadcast(t, src=root, async_op=True) for t in factors[l]]
+    # 3. every rank runs its rows of every layer as the factors land
+    out = []
+    for l, layer in enumerate(layers):
+        if pending[l] is not None:
+            for work in pending[l]:
+                work.wait()  # orders the current stream behind the transfer; no host block on GPU
+        lo, hi = row_range(layer["W"].shape[0], rank, size)
+        shard = backend.run_rows(layer, lo, hi, factors[l])
+        shard["info"] = factors[l][2]
+        out.append(shard)
+    return out
+
+
+def layer_error(shards_row_err, R):
+    """Mean over all R rows of a layer from this rank's row errors (sum-all-reduce of one scalar).
+
+    Bookkeeping outside the timed path: the reference's layer error is the host-side mean.
+    """
+    total = shards_row_err.double().sum()
+    rank, size = world()
+    if size > 1:
+        dist.all_reduce(total)
+    return total / R

@@ -93,20 +93,33 @@ def make_activations(T, n, seed, t0=0):
     return np.rint(x * _FIX) / _FIX
 
 
-def make_hessian(n, seed, T=None, chunk=2048, dead=()):
+def make_hessian(n, seed, T=None, chunk=2048, dead=(), device=None):
     """(H float32 (n, n), mean float32 (n,), T).  Exact integer accumulation in float64.
 
     `dead`: column indices whose activations are forced to zero (inputs that never fire).
+    `device`: a torch device to run the float64 products on (same bytes: the sums are exact
+    integers whatever the order), used by bench.py to set up large layers quickly.
     """
     T = 2 * n if T is None else T
-    acc = np.zeros((n, n), dtype=np.float64)
     col = np.zeros(n, dtype=np.float64)
+    if device is not None:
+        import torch
+
+        acc_t = torch.zeros((n, n), dtype=torch.float64, device=device)
+    else:
+        acc = np.zeros((n, n), dtype=np.float64)
     for t0 in range(0, T, chunk):
         xi = make_activations(min(chunk, T - t0), n, seed, t0) * _FIX  # integers
         if len(dead):
             xi[:, list(dead)] = 0.0
-        acc += xi.T @ xi
+        if device is not None:
+            xt = torch.from_numpy(xi).to(device)
+            acc_t += xt.T @ xt
+        else:
+            acc += xi.T @ xi
         col += xi.sum(axis=0)
+    if device is not None:
+        acc = acc_t.cpu().numpy()
     assert np.abs(acc).max() < 2.0**53
     H = acc / (_FIX * _FIX * T)
     mean = col / (_FIX * T)
@@ -125,8 +138,8 @@ def make_scale(W, levels_hi=1.0, factor=0.6):
     return s.astype(np.float32)
 
 
-def make_layer(R, n, seed, T=None, dead=()):
+def make_layer(R, n, seed, T=None, dead=(), device=None):
     """All inputs of one layer: dict(W, H, mean, scale, T)."""
     W = make_weights(R, n, seed)
-    H, mean, T = make_hessian(n, seed, T=T, dead=dead)
+    H, mean, T = make_hessian(n, seed, T=T, dead=dead, device=device)
     return dict(W=W, H=H, mean=mean, scale=make_scale(W), T=T, seed=seed)

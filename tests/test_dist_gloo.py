@@ -1,0 +1,105 @@
+"""World-size-2 gloo test of the row-shard / rotating-root / broadcast scheduling (no GPU).
+
+sleekit_amd.dist is backend-agnostic: here a stand-in backend makes a layer's "factor" a
+deterministic function of the layer and its "row result" a function of (factor, rows), so
+the test can check on CPU that
+  * every rank receives every layer's factor from the right root (l mod G),
+  * the row ranges tile [0, R) exactly once for ragged R,
+  * a rank's shard equals the single-process result restricted to its rows.
+"""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sleekit_amd import dist as sdist
+
+
+class FakeBackend:
+    def __init__(self):
+        self.factored = []
+
+    def alloc_factor(self, n, device):
+        return (torch.empty(n, dtype=torch.int64), torch.empty((n, n), dtype=torch.float64), torch.empty(1, dtype=torch.int32))
+
+    def factorize(self, layer):
+        n = layer["H"].shape[0]
+        self.factored.append(int(layer["id"]))
+        order = torch.argsort(-layer["H"].diagonal().double(), stable=True)
+        U = torch.triu(layer["H"].double() + layer["id"])
+        return order, U, torch.zeros(1, dtype=torch.int32)
+
+    def run_rows(self, layer, lo, hi, factor):
+        order, U, _ = factor
+        W = layer["W"][lo:hi]
+        Q = (W[:, order].double() @ U).float()
+        return dict(Q=Q, idx=None, row_err=Q.square().sum(dim=1), rows=(lo, hi))
+
+
+def make_layers():
+    g = torch.Generator().manual_seed(7)
+    layers = []
+    for i, (R, n) in enumerate([(10, 6), (7, 5), (9, 4), (5, 8), (11, 3)]):
+        A = torch.randn(n, n, generator=g)
+        layers.append(dict(id=torch.tensor(i), W=torch.randn(R, n, generator=g), H=(A @ A.T).float()))
+    return layers
+
+
+def _worker(rank, size, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        layers = make_layers()
+        be = FakeBackend()
+        shards = sdist.quantize_stream(layers, be)
+        errs = [float(sdist.layer_error(s["row_err"], layers[i]["W"].shape[0])) for i, s in enumerate(shards)]
+        q.put((rank, be.factored, [(s["rows"], s["Q"]) for s in shards], errs))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_row_ranges_tile_exactly():
+    for R in (1, 2, 7, 64, 4096, 4097):
+        for size in (1, 2, 3, 8):
+            spans = [sdist.row_range(R, r, size) for r in range(size)]
+            assert spans[0][0] == 0 and spans[-1][1] == R
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert [sdist.factor_root(l, 8) for l in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
+
+
+@pytest.mark.timeout(120)
+def test_stream_over_gloo_world2():
+    single = sdist.quantize_stream(make_layers(), FakeBackend())  # not initialised: world of one
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=90) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    layers = make_layers()
+    assert got[0][1] == [0, 2, 4] and got[1][1] == [1, 3]  # rotating roots
+    for l, layer in enumerate(layers):
+        R = layer["W"].shape[0]
+        (lo0, hi0), q0 = got[0][2][l]
+        (lo1, hi1), q1 = got[1][2][l]
+        assert (lo0, hi1) == (0, R) and hi0 == lo1
+        assert torch.equal(torch.cat([q0, q1]), single[l]["Q"])  # shards == the unsharded result
+        want = float(single[l]["row_err"].double().sum() / R)
+        assert abs(got[0][3][l] - want) < 1e-9 * abs(want) and got[0][3][l] == got[1][3][l]

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "slk_diag_mean": (c_int, [P, c_int, P, P, c_size_t, P]),
     "slk_probe_mfma_f64": (c_int, [P, c_int, c_int, P]),
     "slk_probe_mfma_f32": (c_int, [P, c_int, c_int, P]),
+    "slk_probe_chain": (c_int, [P, c_int, c_int, P]),
     "slk_profile_enable": (c_int, [c_int]),
     "slk_profile_reset": (c_int, []),
     "slk_profile_report": (c_int, [c_char_p, c_size_t]),

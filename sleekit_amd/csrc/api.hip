@@ -33,11 +33,59 @@ __global__ __launch_bounds__(256) void k_probe_f32(float *sink, int iters) {
     if (tot == 12345.678f) sink[0] = tot;
 }
 
+// Latency / issue-rate probe for the scalar-per-lane float64 pipeline (the leaf chain and the
+// panel factorisation are dependency chains on it).  One wave; out[0] = shader cycles
+// (s_memtime), out[1] = 100 MHz ticks (s_memrealtime), out[2] = checksum.
+__global__ __launch_bounds__(64) void k_probe_chain(double *out, int iters, int mode) {
+    double x0 = 1.0 + threadIdx.x * 1e-9, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    const double a = 1.0000001, b = 1e-9;
+    float f = 1.0f + threadIdx.x * 1e-6f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#define CHAIN(BODY)                                  \
+    for (int i = 0; i < iters; i += 8) {             \
+        BODY BODY BODY BODY BODY BODY BODY BODY      \
+    }
+    if (mode == 0) {
+        CHAIN(x0 = __builtin_fma(x0, a, b);)
+    } else if (mode == 1) {
+        CHAIN(x0 = __builtin_fma(x0, a, b); x1 = __builtin_fma(x1, a, b); x2 = __builtin_fma(x2, a, b); x3 = __builtin_fma(x3, a, b);
+              x4 = __builtin_fma(x4, a, b); x5 = __builtin_fma(x5, a, b); x6 = __builtin_fma(x6, a, b); x7 = __builtin_fma(x7, a, b);)
+    } else if (mode == 2) {
+        CHAIN(f = __builtin_fmaf(f, 1.0000001f, 1e-9f);)
+    } else if (mode == 3) {
+        CHAIN(x0 = __builtin_amdgcn_rsq(x0) + 1.0;)
+    } else if (mode == 4) {
+        CHAIN(x0 = 1.0 / x0 + 0.5;)
+    } else if (mode == 5) {
+        CHAIN(f = 1.0f / f + 0.5f;)
+    } else if (mode == 6) {
+        CHAIN(x0 = (double)(float)x0 * a;)
+    } else if (mode == 7) {
+        CHAIN(x0 = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(x0) >> 32), 5) << 32) | 7) * a;)
+    } else {
+        CHAIN(f = rintf(f * 1.0000001f) + 0.25f;)
+    }
+#undef CHAIN
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = (double)(t1 - t0);
+        out[1] = (double)(r1 - r0);
+        out[2] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + f;
+    }
+}
+
 }  // namespace slk
 
 using namespace slk;
 
 extern "C" {
+
+int slk_probe_chain(double *out, int iters, int mode, slk_stream_t stream) {
+    SLK_REQUIRE(out && iters > 0, "bad arguments");
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("probe_chain", 0, 0, s, k_probe_chain<<<1, 64, 0, s>>>(out, iters, mode));
+    return SLK_OK;
+}
 
 size_t slk_workspace_bytes(int R, int n) {
     if (R < 0 || n <= 0) return 0;

@@ -14,6 +14,8 @@
 //   3. U[i][j] = X[n-1-i][n-1-j]  (index reversal back; upper triangular).
 //
 // All products run on v_mfma_f64_16x16x4_f64 through mfma64.h.
+#include <stdlib.h>
+
 #include "mfma64.h"
 
 namespace slk {
@@ -23,65 +25,123 @@ constexpr int OUTER = 256;
 constexpr int DP = 65;  // pitch of the 64 x 64 LDS tiles (odd: column walks are conflict-free)
 
 struct PanelSmem {
-    double d[PANEL][DP];   // diagonal tile -> L11
-    double x[PANEL][DP];   // inv(L11)
+    double d[PANEL][DP];      // staging of the diagonal tile, then L11
+    double x[PANEL][DP];      // inv(L11)
+    double col[2][4][PANEL];  // column j as seen by each wave (only the owner's slot is read)
+    double row[2][2 * PANEL]; // row tt of the inverse being propagated, wave-major (+ a dump area)
+    double rdiag[PANEL];      // 1 / L11[j][j]
     Tile64Smem mm;
 };
 
+// 1/sqrt(d) to double precision: hardware estimate + two Newton steps (3 dependent ops each).
+__device__ __forceinline__ double rsqrt_newton(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = __builtin_fma(-(d * y), y, 1.0);
+        y = __builtin_fma(0.5 * y, e, y);
+    }
+    return y;
+}
+
 // Panel step at column k0: block 0 publishes inv(L11) into X; block b >= 1 overwrites the
-// tile A[k0 + 64 b ..][k0 ..] with L21.
+// tile A[k0 + 64 b ..][k0 ..] with L21 = A21 * inv(L11)^T.
+//
+// The 64 x 64 diagonal tile lives in REGISTERS: thread (i = t & 63, q = t >> 6) holds row i,
+// columns q, q+4, ..., q+60, so wave q is one residue class of columns and its lanes are the
+// rows.  Right-looking elimination, one barrier per column, a refined rsqrt instead of
+// sqrt + divide.  A taken branch costs ~45 cycles on this chip and this loop is a pure
+// latency chain, so both loops are FULLY UNROLLED and branch-free: column/step numbers are
+// compile-time constants (static register indices, statically known triangular extents),
+// every wave publishes its candidate for column j into its own LDS slot and readers index
+// the owner's slot, failures are folded into a flag that is stored once at the end.
+// The inverse is a forward substitution on all 64 right-hand sides with the same layout.
 __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int ld, int k0,
                                                     double *__restrict__ X, int *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PanelSmem &sm = *reinterpret_cast<PanelSmem *>(smem_raw);
     const int t = threadIdx.x;
+    const int i = t & 63, q = t >> 6;
 
-    // ---- load the diagonal tile (lower part; upper part cleared)
+    // ---- stage the tile coalesced, then pick this thread's row slice out of LDS
     for (int e = t; e < PANEL * PANEL; e += 256) {
-        const int i = e >> 6, j = e & 63;
-        sm.d[i][j] = (j <= i) ? A[(size_t)(k0 + i) * ld + k0 + j] : 0.0;
-        sm.x[i][j] = 0.0;
-    }
-    // ---- unblocked right-looking Cholesky in LDS
-    for (int j = 0; j < PANEL; ++j) {
-        __syncthreads();
-        double piv = sm.d[j][j];
-        if (!(piv > 0.0)) {  // also catches NaN
-            if (blockIdx.x == 0 && t == 0 && info[0] == 0) info[0] = k0 + j + 1;
-            piv = 1.0;
-        }
-        const double s = sqrt(piv);
-        const double inv = 1.0 / s;
-        __syncthreads();
-        if (t < PANEL) {
-            if (t == j) sm.d[j][j] = s;
-            else if (t > j) sm.d[t][j] = sm.d[t][j] * inv;
-        }
-        __syncthreads();
-        // trailing update of the tile: columns c > j, rows i >= c
-        const int i = t & 63;
-        for (int c = j + 1 + (t >> 6); c < PANEL; c += 4)
-            if (i >= c) sm.d[i][c] = sm.d[i][c] - sm.d[i][j] * sm.d[c][j];
+        const int r = e >> 6, c = e & 63;
+        sm.d[r][c] = (c <= r) ? A[(size_t)(k0 + r) * ld + k0 + c] : 0.0;
     }
     __syncthreads();
-    // ---- X11 = inv(L11): right-looking forward substitution on all columns at once.
-    //      sm.x accumulates sum_t L[i][t] X[t][c]; row tt is finalised at step tt.
+    double a[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) a[m] = sm.d[i][q + 4 * m];
+
+    // ---- Cholesky of the tile
+    int first_bad = PANEL;
+#pragma unroll
+    for (int j = 0; j < PANEL; ++j) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int jq = j & 3, jm = j >> 2, buf = j & 1;
+        sm.col[buf][q][i] = a[jm];  // only wave jq's slot holds column j
+        __syncthreads();
+        double piv = sm.col[buf][jq][j];
+        const double mine = sm.col[buf][jq][i];
+        double lc[16];
+#pragma unroll
+        for (int m = jm; m < 16; ++m) lc[m] = sm.col[buf][jq][q + 4 * m];
+        const bool bad = !(piv > 0.0);  // also catches NaN
+        first_bad = (bad && first_bad == PANEL) ? j : first_bad;
+        piv = bad ? 1.0 : piv;
+        const double r = rsqrt_newton(piv);
+        const double lij = (i < j) ? 0.0 : mine * r;  // i == j: piv * r = sqrt(piv)
+        sm.rdiag[j] = r;                              // same value from every thread
+        // element jm: the owner stores L, waves to its right (column q + 4 jm > j) update
+        {
+            const double upd = __builtin_fma(-lij, lc[jm] * r, a[jm]);
+            a[jm] = (q == jq) ? lij : ((q > jq) ? upd : a[jm]);
+        }
+#pragma unroll
+        for (int m = jm + 1; m < 16; ++m) a[m] = __builtin_fma(-lij, lc[m] * r, a[m]);
+    }
+    if (first_bad != PANEL && blockIdx.x == 0 && t == 0 && info[0] == 0) info[0] = k0 + first_bad + 1;
+    // ---- L11 to LDS (lower part) for the substitution
+#pragma unroll
+    for (int m = 0; m < 16; ++m) sm.d[i][q + 4 * m] = (q + 4 * m <= i) ? a[m] : 0.0;
+    __syncthreads();
+
+    // ---- X11 = inv(L11): x[m] accumulates sum_t L[i][t] X[t][c] for c = q + 4m.
+    //      Step tt touches only columns c <= tt, i.e. m <= tt >> 2 (m == tt >> 2 iff q <= tt & 3).
+    double x[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = 0.0;
+#pragma unroll
     for (int tt = 0; tt < PANEL; ++tt) {
-        if (t <= tt) {
-            const double acc = sm.x[tt][t];
-            sm.x[tt][t] = ((t == tt ? 1.0 : 0.0) - acc) / sm.d[tt][tt];
+        const int tq = tt & 3, tm = tt >> 2, buf = tt & 1;
+        const double rd = sm.rdiag[tt];
+        const bool fin = i == tt;  // one lane per wave finalises its entries of row tt
+#pragma unroll
+        for (int m = 0; m <= tm; ++m) {
+            const double unit = (m == tm) ? ((q == tq) ? 1.0 : 0.0) : 0.0;
+            const double xv = (unit - x[m]) * rd;
+            const bool live = (m < tm) || (q <= tq);
+            x[m] = (fin && live) ? xv : x[m];
+            sm.row[buf][fin ? q * 16 + m : PANEL + i] = xv;  // other lanes write to a dump slot: no branch
         }
         __syncthreads();
-        const int c = t & 63;
-        if (c <= tt)
-            for (int i = tt + 1 + (t >> 6); i < PANEL; i += 4) sm.x[i][c] = sm.x[i][c] + sm.d[i][tt] * sm.x[tt][c];
-        __syncthreads();
+        const double l = (i > tt) ? sm.d[i][tt] : 0.0;
+#pragma unroll
+        for (int m = 0; m <= tm; ++m) {
+            const double xr = sm.row[buf][q * 16 + m];
+            const bool live = (m < tm) || (q <= tq);
+            x[m] = live ? __builtin_fma(l, xr, x[m]) : x[m];  // l == 0 for rows already final
+        }
     }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) sm.x[i][q + 4 * m] = x[m];  // exactly zero above the diagonal
+    __syncthreads();
 
     if (blockIdx.x == 0) {
         for (int e = t; e < PANEL * PANEL; e += 256) {
-            const int i = e >> 6, j = e & 63;
-            X[(size_t)(k0 + i) * ld + k0 + j] = sm.x[i][j];  // upper part is exactly zero
+            const int r = e >> 6, c = e & 63;
+            X[(size_t)(k0 + r) * ld + k0 + c] = sm.x[r][c];
         }
         return;
     }

@@ -11,6 +11,9 @@
 // Numerics follow the reference exactly: float32 quantizer (true divide, rint, separate
 // multiply/add), err = float64(w - q) / U[i][i], rank-1 and block updates in float64
 // (product rounded, then subtraction rounded), one rounding to float32 per update.
+#include <stdlib.h>
+#include <string.h>
+
 #include <vector>
 
 #include "mfma64.h"
@@ -72,13 +75,85 @@ struct WindowSmem {
     double u[ULEAF][ULEAF + 1];
 };
 
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// codebook.py:56-65 with the divide replaced by Markstein's sequence: with y = RN(1/step),
+//   q0 = RN(t0 y);  r = t0 - step q0 (exact in one fma);  t = RN(q0 + r y) == RN(t0 / step)
+// for every t0 whose quotient neither overflows nor underflows (rint of an underflowing
+// quotient is 0 either way).  Saves ~40 dependent cycles per column on the leaf's critical
+// path.  tests/test_gpu_parity.py::test_fast_quantizer_matches_true_divide sweeps it against
+// the true-divide kernel.
+__device__ __forceinline__ float grid_value_fast(float x, const Grid g, float inv_step) {
+    const float t0 = x - g.zero;
+    const float q0 = t0 * inv_step;
+    const float r = __builtin_fmaf(-g.step, q0, t0);
+    float t = __builtin_fmaf(r, inv_step, q0);
+    t = rintf(t);
+    t = fminf(fmaxf(t, 0.0f), g.top);
+    return t * g.step + g.zero;
+}
+
+// LEAF, register path (width <= 32, window in LDS).  A wave owns two rows, 32 lanes per row;
+// lane c keeps column a + c of its row in a register together with U[a + i][a + c], i < 32.
+// Step i: the value of column i is read-laned to every lane of its half-wave, all of them
+// compute q_i and err_i redundantly (no second broadcast), then update their own column:
+//     x_c <- float32(float64(x_c) - err_i * U[i][c])                      (obq.py:114-118)
+// err_i = float64(x_i - q_i) / U[i][i] uses the same exact-division sequence in float64 with
+// the reciprocals taken once per leaf by true division.
+__device__ __forceinline__ bool leaf_registers(WindowSmem &sm, int row, int lane, int a_rel, int w, const Grid g,
+                                               float inv_step) {
+    const int l32 = lane & 31;
+    const bool mine = l32 < w;
+    const double uc = mine ? sm.u[l32][l32] : 1.0;
+    // Markstein's exception: a divisor whose significand is all ones
+    const bool odd = (__double_as_longlong(uc) & 0xFFFFFFFFFFFFFLL) == 0xFFFFFFFFFFFFFLL;
+    if (__any(odd)) return false;
+    const double rc = 1.0 / uc;
+    float x = mine ? sm.q[row][a_rel + l32] : 0.0f;
+    double u[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) u[i] = (i < w && mine && l32 > i) ? sm.u[i][l32] : 0.0;
+    float qfin = 0.0f, efin = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < w) {  // uniform
+            const int xb = __float_as_int(x);
+            const float xa = __int_as_float(__builtin_amdgcn_readlane(xb, i));
+            const float xbv = __int_as_float(__builtin_amdgcn_readlane(xb, 32 + i));
+            const float xi = lane < 32 ? xa : xbv;
+            const double uii = readlane_f64(uc, i), rii = readlane_f64(rc, i);
+            const float q = grid_value_fast(xi, g, inv_step);
+            const double d = (double)(xi - q);
+            const double q0 = d * rii;
+            const double rem = __builtin_fma(-uii, q0, d);
+            const double err = __builtin_fma(rem, rii, q0);
+            if (l32 == i) {
+                qfin = q;
+                efin = (float)err;
+            }
+            const double p = err * u[i];
+            x = (float)((double)x - p);
+        }
+    }
+    if (mine) {
+        sm.q[row][a_rel + l32] = qfin;
+        sm.e[row][a_rel + l32] = efin;
+    }
+    return true;
+}
+
 // One workgroup = 512 threads = 8 waves = RB rows.  In a LEAF each wave owns two rows,
-// 32 lanes per row: lane c updates column i+1+c after column i is fixed.  In an UPDATE the
-// 8 waves split the target columns in 16-wide MFMA blocks (M = the 16 rows of the tile).
+// 32 lanes per row.  In an UPDATE the 8 waves split the target columns in 16-wide MFMA
+// blocks (M = the 16 rows of the tile), two blocks in flight per wave, K in chunks of 64.
 template <bool IN_LDS>
 __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, float *__restrict__ Eg,
                                                      const double *__restrict__ U, int R, int n, int w0, int w1,
-                                                     Grid g, OpTable tab) {
+                                                     Grid g, float inv_step, int fast_ok, OpTable tab) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     WindowSmem &sm = *reinterpret_cast<WindowSmem *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -92,8 +167,25 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
     auto eref = [&](int r, int c) -> volatile float & {
         return IN_LDS ? *(volatile float *)&sm.e[r][c - w0] : *(volatile float *)&Eg[(size_t)(r0 + r) * n + c];
     };
+    // Register prefetch of the next staged leaf's U block (<= 32 x 32 doubles over 512 threads).
+    double pu[2] = {0.0, 0.0};
+    auto prefetch_leaf = [&](int from) {
+        for (int oj = from; oj < tab.count; ++oj) {
+            const Op nx = tab.op[oj];
+            if (nx.kind != OP_LEAF) continue;
+            const int w = nx.b - nx.a;
+            if (w > ULEAF) return;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = t + 512 * h;
+                if (e < w * w) pu[h] = U[(size_t)(nx.a + e / w) * n + nx.a + e % w];
+            }
+            return;
+        }
+    };
 
     if (IN_LDS) {
+        prefetch_leaf(0);
         for (int e = t; e < RB * width; e += 512) {
             const int r = e / width, c = e % width;
             sm.q[r][c] = (r0 + r < R) ? Qp[(size_t)(r0 + r) * n + w0 + c] : 0.0f;
@@ -105,17 +197,21 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
         const Op op = tab.op[oi];
         if (op.kind == OP_LEAF) {
             const int a = op.a, b = op.b, w = b - a;
-            const bool staged = w <= ULEAF;
+            const bool staged = IN_LDS && w <= ULEAF;
             if (staged) {
-                for (int e = t; e < w * w; e += 512) {
-                    const int i = e / w, j = e % w;
-                    sm.u[i][j] = U[(size_t)(a + i) * n + a + j];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = t + 512 * h;
+                    if (e < w * w) sm.u[e / w][e % w] = pu[h];
                 }
             }
             __syncthreads();
+            if (IN_LDS) prefetch_leaf(oi + 1);  // flies during this leaf and the update behind it
             const int row = 2 * wave + (lane >> 5), l32 = lane & 31;
+            bool done = false;
+            if (staged && fast_ok) done = leaf_registers(sm, row, lane, a - w0, w, g, inv_step);
             const bool live = IN_LDS || (r0 + row < R);
-            if (live) {
+            if (!done && live) {
                 for (int i = a; i < b; ++i) {
                     const float x = qref(row, i);
                     const float q = grid_value(x, g);
@@ -140,29 +236,42 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
             const int a = op.a, b = op.b, c = op.c;
             const int nblk = (c - b + 15) / 16;
             const int lr = lane & 15, lk = lane >> 4;
-            for (int blk = wave; blk < nblk; blk += 8) {
-                const int col = b + blk * 16 + lr;
-                const bool col_ok = col < c;
-                double4_t acc = {0.0, 0.0, 0.0, 0.0};
-                for (int k0 = a; k0 < b; k0 += 16) {
-                    double av[4], bv[4];
+            const bool row_ok = IN_LDS || r0 + lr < R;
+            for (int blk0 = wave; blk0 < nblk; blk0 += 16) {
+                const int blk1 = blk0 + 8;
+                const int col0 = b + blk0 * 16 + lr, col1 = b + blk1 * 16 + lr;
+                const bool ok0 = col0 < c, ok1 = blk1 < nblk && col1 < c;
+                double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                for (int k0 = a; k0 < b; k0 += 64) {
+                    double av[16], b0[16], b1[16];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
+                    for (int s = 0; s < 16; ++s) {
                         const int k = k0 + 4 * s + lk;
                         const bool k_ok = k < b;
-                        av[s] = (k_ok && (IN_LDS || r0 + lr < R)) ? (double)eref(lr, k) : 0.0;
-                        bv[s] = (k_ok && col_ok) ? U[(size_t)k * n + col] : 0.0;
+                        b0[s] = (k_ok && ok0) ? U[(size_t)k * n + col0] : 0.0;
+                        b1[s] = (k_ok && ok1) ? U[(size_t)k * n + col1] : 0.0;
+                        av[s] = (k_ok && row_ok) ? (double)eref(lr, k) : 0.0;
                     }
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
-                }
-                if (col_ok) {
+                    for (int s = 0; s < 16; ++s)
+                        if (k0 + 4 * s < b) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], b0[s], acc0, 0, 0, 0);
+                    if (blk1 < nblk) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = lk + 4 * r;
-                        if (IN_LDS || r0 + row < R) {
-                            const double v = (double)qref(row, col);
-                            qref(row, col) = (float)(v - acc[r]);
+                        for (int s = 0; s < 16; ++s)
+                            if (k0 + 4 * s < b) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], b1[s], acc1, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = lk + 4 * r;
+                    if (IN_LDS || r0 + row < R) {
+                        if (ok0) {
+                            const double v = (double)qref(row, col0);
+                            qref(row, col0) = (float)(v - acc0[r]);
+                        }
+                        if (ok1) {
+                            const double v = (double)qref(row, col1);
+                            qref(row, col1) = (float)(v - acc1[r]);
                         }
                     }
                 }
@@ -269,6 +378,12 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
     }
     hipStream_t s = as_stream(stream);
     const Grid g = make_grid(levels, lo, hi);
+    // exact-division shortcut of the leaf: needs a sane step whose significand is not all ones
+    const float inv_step = 1.0f / g.step;
+    unsigned step_bits;
+    memcpy(&step_bits, &g.step, 4);
+    const int fast_ok = (step_bits & 0x7FFFFFu) != 0x7FFFFFu && g.step > 9.0e-13f && g.step < 1.0e12f &&
+                        getenv("SLK_NO_FAST_LEAF") == nullptr;
     static bool attr_set = false;
     if (!attr_set) {
         SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gptq_window<true>),
@@ -303,10 +418,12 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
                 const double wbytes = 12.0 * R * (st.b - st.a) + ub;  // Q in/out + E out, U once
                 if (in_lds)
                     SLK_RUN("gptq_window", fl * R, wbytes, s,
-                            k_gptq_window<true><<<row_tiles, 512, sizeof(WindowSmem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g, tab));
+                            k_gptq_window<true><<<row_tiles, 512, sizeof(WindowSmem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g,
+                                                                                        inv_step, fast_ok, tab));
                 else
                     SLK_RUN("gptq_window_wide", fl * R, wbytes, s,
-                            k_gptq_window<false><<<row_tiles, 512, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, g, tab));
+                            k_gptq_window<false><<<row_tiles, 512, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, g, inv_step, fast_ok,
+                                                                           tab));
             }
         } else {
             dim3 grid((st.c - st.b + TILE - 1) / TILE, (R + TILE - 1) / TILE);

@@ -45,6 +45,12 @@ class HipBackend:
         self.engine, self.quantizer = engine, quantizer
         self.act_order, self.damp, self.moves, self.with_error = act_order, damp, nb_ls_moves, with_error
 
+    def streams(self):
+        """(factor stream, comm stream), created once per backend."""
+        if not hasattr(self, "_streams"):
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        return self._streams
+
     def alloc_factor(self, n, device):
         return (
             torch.empty(n, dtype=torch.int64, device=device),
@@ -72,38 +78,76 @@ class HipBackend:
         return dict(Q=res.Q, idx=res.idx, row_err=err, rows=(lo, hi))
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def quantize_stream(layers, backend, comm_device=None):
     """Quantize `layers` (list of dicts with W (R, n), H (n, n), optional scale (R,)) across the ranks.
 
     Returns, per layer, this rank's shard: dict(Q, idx, row_err, rows=(lo, hi), info).
     Every rank holds every layer's inputs (W, H are inputs of the path and resident before
     it starts); only the factor travels.
+
+    Three queues per rank when the backend provides device streams (`backend.streams()`):
+      factor stream : the n x n factorisations this rank owns, back to back
+      comm stream   : one broadcast per layer, each behind its factor's event
+      main stream   : the row loops, each behind its layer's factor / broadcast
+    so the latency-bound factorisation of layer l+1 runs under the loop and error of layer l.
     """
     rank, size = world()
     n_layers = len(layers)
     factors = [None] * n_layers
+    ready = [None] * n_layers
+    fstream, cstream = backend.streams() if hasattr(backend, "streams") else (None, None)
+
+    def on(stream):
+        return torch.cuda.stream(stream) if stream is not None else _NullCtx()
+
     # 1. every rank factors the layers it is the root of (concurrently across ranks)
-    for l in range(rank, n_layers, size):
-        factors[l] = backend.factorize(layers[l])
+    if fstream is not None:
+        fstream.wait_stream(torch.cuda.current_stream())
+    with on(fstream):
+        for l in range(rank, n_layers, size):
+            factors[l] = backend.factorize(layers[l])
+            if fstream is not None:
+                ready[l] = torch.cuda.Event()
+                ready[l].record(fstream)
     # 2. one asynchronous broadcast per layer from its root, issued in layer order
     pending = [None] * n_layers
     if size > 1:
-        for l in range(n_layers):
-            root = factor_root(l, size)
-            if root != rank:
-                dev = comm_device if comm_device is not None else layers[l]["H"].device
-                factors[l] = backend.alloc_factor(layers[l]["H"].shape[0], dev)
-            pending[l] = [dist.broadcast(t, src=root, async_op=True) for t in factors[l]]
+        if cstream is not None:
+            cstream.wait_stream(torch.cuda.current_stream())
+        with on(cstream):
+            for l in range(n_layers):
+                root = factor_root(l, size)
+                if root != rank:
+                    dev = comm_device if comm_device is not None else layers[l]["H"].device
+                    factors[l] = backend.alloc_factor(layers[l]["H"].shape[0], dev)
+                elif ready[l] is not None:
+                    cstream.wait_event(ready[l])
+                pending[l] = [dist.broadcast(t, src=root, async_op=True) for t in factors[l]]
     # 3. every rank runs its rows of every layer as the factors land
     out = []
     for l, layer in enumerate(layers):
         if pending[l] is not None:
             for work in pending[l]:
                 work.wait()  # orders the current stream behind the transfer; no host block on GPU
+        elif ready[l] is not None:
+            torch.cuda.current_stream().wait_event(ready[l])
         lo, hi = row_range(layer["W"].shape[0], rank, size)
         shard = backend.run_rows(layer, lo, hi, factors[l])
         shard["info"] = factors[l][2]
         out.append(shard)
+    if fstream is not None:
+        # tensors made on the side streams are consumed on the main stream: keep the allocator honest
+        for f in factors:
+            for t in f:
+                t.record_stream(torch.cuda.current_stream())
     return out
 
 

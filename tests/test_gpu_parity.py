@@ -186,6 +186,30 @@ def test_loop_blockings_match_oracle(amd, min_block, num_blocks):
     np.testing.assert_allclose(E1, E0, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("levels,lo,hi", [(2, -1, 1), (3, -1, 1), (4, -1, 1), (8, -1, 1), (16, -1, 1), (256, -1, 1), (5, -0.75, 1.25), (7, 0.0, 3.0)])
+def test_fast_quantizer_matches_true_divide(amd, levels, lo, hi):
+    """The leaf kernel replaces the float32 divide by an exact-division fma sequence; with an
+    identity factor the loop degenerates to q(W), which must equal the true-divide codebook
+    kernel bit for bit -- on random values and on values a few ulps around every rounding tie."""
+    cb = amd.codebook.UniformCodebook(levels, lo, hi)
+    step = np.float32((hi - lo) / (levels - 1))
+    rng = np.random.default_rng(levels)
+    ties = (np.float32(lo) + (np.arange(-2, levels + 2, dtype=np.float32) + np.float32(0.5)) * step).astype(np.float32)
+    near, up, down = [ties], ties, ties
+    for _ in range(6):  # up to six ulps on either side of every tie (finite values only)
+        up, down = np.nextafter(up, np.float32(np.inf)), np.nextafter(down, np.float32(-np.inf))
+        near += [up.astype(np.float32), down.astype(np.float32)]
+    near = np.concatenate(near)
+    body = (rng.standard_normal(512 * 2048) * 0.7 * (hi - lo) + (hi + lo) / 2).astype(np.float32)
+    W = np.concatenate([near, body])[: 512 * 2048].reshape(512, 2048).copy()
+    W.reshape(-1)[: len(near)] = near[: W.size]
+    Q, E = W.copy(), np.zeros_like(W)
+    amd.obq._quantize_opt_block(Q, E, np.eye(2048), cb, 32, 8)
+    want = cb.quantize_value(W)
+    assert np.array_equal(Q, want)
+    assert np.array_equal(E, W - want)
+
+
 def test_small_cases_bit_exact(amd, small_cases):
     names = [str(x) for x in small_cases["names"]]
     bad = []

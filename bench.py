@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic layers cycled through the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--streams", type=str, default="3,2", help="factor,loop stream counts")
     ap.add_argument("--stages", action="store_true", help="also print per-kernel timing table to stderr")
     return ap.parse_args()
 
@@ -95,7 +96,8 @@ def main():
         host_layer0 = {k: base[0][k].cpu().numpy() for k in ("W", "H", "scale")}
     t_setup = time.time() - t_setup
 
-    backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True)
+    backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True,
+                               overlap=tuple(int(x) for x in args.streams.split(",")))
 
     def step():
         shards = sdist.quantize_stream(layers, backend)
@@ -132,7 +134,8 @@ def main():
         fence()
         _lib.lib.slk_profile_reset()
         _lib.lib.slk_profile_enable(1)
-        step()
+        # one stream for this pass: kernels of different layers must not share the chip while timed
+        sdist.quantize_stream(layers, sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=False))
         torch.cuda.synchronize()
         _lib.lib.slk_profile_enable(0)
         table = _lib.profile_report()

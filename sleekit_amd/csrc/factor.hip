@@ -150,9 +150,14 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
     Acc64 acc;
     acc.zero();
     const double *arow = A + (size_t)r0 * ld + k0;
-    tile64_mac<true, true>(
-        acc, sm.mm, 0, PANEL, [&](int r, int k) { return arow[(size_t)r * ld + k]; },
-        [&](int k, int c) { return sm.x[c][k]; });
+    const double *pa = arow + (size_t)(t >> 2) * ld + (t & 3) * 8;
+    tile64_mac<false>(
+        acc, sm.mm, 0, PANEL, [&](int kb, double(&v)[8]) { load8d<true>(pa + kb, v); },
+        [&](int kb, double(&v)[8]) {  // B[k][c] = X11[c][k], straight from LDS
+            const double *px = &sm.x[t >> 2][kb + (t & 3) * 8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = px[e];
+        });
     __syncthreads();
     tile64_foreach(acc, [&](int r, int c, double v) { A[(size_t)(r0 + r) * ld + k0 + c] = v; });
 }
@@ -160,16 +165,17 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
 // C[bi][bj] -= L[bi][ka:kb] * L[bj][ka:kb]^T for tiles bi in [ti0, ti1), bj in [tj0, tj1), bj <= bi.
 __global__ __launch_bounds__(256) void k_syrk_tiles(double *__restrict__ A, int ld, int ti0, int tj0, int ka,
                                                     int kb) {
-    __shared__ Tile64Smem sm;
+    __shared__ __attribute__((aligned(16))) Tile64Smem sm;
     const int bi = ti0 + blockIdx.y, bj = tj0 + blockIdx.x;
     if (bj > bi) return;
     Acc64 acc;
     acc.zero();
-    const double *pa = A + (size_t)bi * TILE * ld;
-    const double *pb = A + (size_t)bj * TILE * ld;
-    tile64_mac<true, false>(
-        acc, sm, ka, kb, [&](int r, int k) { return pa[(size_t)r * ld + k]; },
-        [&](int k, int c) { return pb[(size_t)c * ld + k]; });
+    const int t = threadIdx.x;
+    const double *pa = A + ((size_t)bi * TILE + (t >> 2)) * ld + (t & 3) * 8;
+    const double *pb = A + ((size_t)bj * TILE + (t >> 2)) * ld + (t & 3) * 8;
+    tile64_mac<false>(
+        acc, sm, ka, kb, [&](int k0, double(&v)[8]) { load8d<true>(pa + k0, v); },
+        [&](int k0, double(&v)[8]) { load8d<true>(pb + k0, v); });
     double *pc = A + (size_t)bi * TILE * ld + (size_t)bj * TILE;
     tile64_foreach(acc, [&](int r, int c, double v) { pc[(size_t)r * ld + c] -= v; });
 }
@@ -180,26 +186,27 @@ __global__ __launch_bounds__(256) void k_syrk_tiles(double *__restrict__ A, int 
 template <int STAGE>
 __global__ __launch_bounds__(256) void k_trtri_level(const double *__restrict__ L, double *__restrict__ X,
                                                      double *__restrict__ S, int ld, int nt, int s) {
-    __shared__ Tile64Smem sm;
+    __shared__ __attribute__((aligned(16))) Tile64Smem sm;
     const int bi = blockIdx.y, bj = blockIdx.x;
     const int lo = bi / (2 * s) * (2 * s), mid = lo + s;
     if (bi < mid || bj < lo || bj >= mid) return;
     Acc64 acc;
     acc.zero();
+    const int t = threadIdx.x;
     if (STAGE == 0) {
-        const double *pa = L + (size_t)bi * TILE * ld;
-        const double *pb = X + (size_t)bj * TILE;
-        tile64_mac<true, true>(
-            acc, sm, bj * TILE, mid * TILE, [&](int r, int k) { return pa[(size_t)r * ld + k]; },
-            [&](int k, int c) { return pb[(size_t)k * ld + c]; });
+        const double *pa = L + ((size_t)bi * TILE + (t >> 2)) * ld + (t & 3) * 8;
+        const double *pb = X + (size_t)(t >> 3) * ld + (size_t)bj * TILE + (t & 7) * 8;
+        tile64_mac<true>(
+            acc, sm, bj * TILE, mid * TILE, [&](int k0, double(&v)[8]) { load8d<true>(pa + k0, v); },
+            [&](int k0, double(&v)[8]) { load8d<true>(pb + (size_t)k0 * ld, v); });
         double *pc = S + (size_t)bi * TILE * ld + (size_t)bj * TILE;
         tile64_foreach(acc, [&](int r, int c, double v) { pc[(size_t)r * ld + c] = v; });
     } else {
-        const double *pa = X + (size_t)bi * TILE * ld;
-        const double *pb = S + (size_t)bj * TILE;
-        tile64_mac<true, true>(
-            acc, sm, mid * TILE, (bi + 1) * TILE, [&](int r, int k) { return pa[(size_t)r * ld + k]; },
-            [&](int k, int c) { return pb[(size_t)k * ld + c]; });
+        const double *pa = X + ((size_t)bi * TILE + (t >> 2)) * ld + (t & 3) * 8;
+        const double *pb = S + (size_t)(t >> 3) * ld + (size_t)bj * TILE + (t & 7) * 8;
+        tile64_mac<true>(
+            acc, sm, mid * TILE, (bi + 1) * TILE, [&](int k0, double(&v)[8]) { load8d<true>(pa + k0, v); },
+            [&](int k0, double(&v)[8]) { load8d<true>(pb + (size_t)k0 * ld, v); });
         double *pc = X + (size_t)bi * TILE * ld + (size_t)bj * TILE;
         tile64_foreach(acc, [&](int r, int c, double v) { pc[(size_t)r * ld + c] = -v; });
     }

@@ -295,16 +295,35 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
 // Qp[:, ja:jb] = float32(float64(Qp[:, ja:jb]) - E[:, ka:kb] @ U[ka:kb, ja:jb]), 64 x 64 tiles.
 __global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, const float *__restrict__ Eg,
                                                        const double *__restrict__ U, int R, int n, int ka, int kb,
-                                                       int ja, int jb) {
-    __shared__ Tile64Smem sm;
+                                                       int ja, int jb, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) Tile64Smem sm;
     const int r0 = blockIdx.y * TILE, j0 = ja + blockIdx.x * TILE;
+    const int t = threadIdx.x;
     Acc64 acc;
     acc.zero();
     const int kend = ka + (kb - ka + KSTEP - 1) / KSTEP * KSTEP;
-    tile64_mac<true, true>(
-        acc, sm, ka, kend,
-        [&](int r, int k) { return (r0 + r < R && k < kb) ? (double)Eg[(size_t)(r0 + r) * n + k] : 0.0; },
-        [&](int k, int c) { return (k < kb && j0 + c < jb) ? U[(size_t)k * n + j0 + c] : 0.0; });
+    const int a_row = r0 + (t >> 2), a_k = (t & 3) * 8;  // A = E (float32), K contiguous
+    const int b_k = t >> 3, b_col = j0 + (t & 7) * 8;    // B = U (float64), columns contiguous
+    if (vec_ok && r0 + TILE <= R && j0 + TILE <= jb && kend == kb) {
+        const float *pe = Eg + (size_t)a_row * n + a_k;
+        const double *pu = U + (size_t)b_k * n + b_col;
+        tile64_mac<true>(
+            acc, sm, ka, kend, [&](int k0, double(&v)[8]) { load8f_as_d<true>(pe + k0, v); },
+            [&](int k0, double(&v)[8]) { load8d<true>(pu + (size_t)k0 * n, v); });
+    } else {
+        const bool row_ok = a_row < R;
+        const float *pe = Eg + (size_t)min(a_row, R - 1) * n;
+        tile64_mac<true>(
+            acc, sm, ka, kend,
+            [&](int k0, double(&v)[8]) {
+                const int k = k0 + a_k;
+                load8f_as_d_guarded(pe + min(k, kb - 1), kb - 1 - k, row_ok, v);
+            },
+            [&](int k0, double(&v)[8]) {
+                const int k = k0 + b_k;
+                load8d_guarded(U + (size_t)min(k, kb - 1) * n + min(b_col, jb - 1), jb - 1 - b_col, k < kb, v);
+            });
+    }
     tile64_foreach(acc, [&](int r, int c, double v) {
         if (r0 + r < R && j0 + c < jb) {
             float *p = Qp + (size_t)(r0 + r) * n + j0 + c;
@@ -429,7 +448,8 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
             dim3 grid((st.c - st.b + TILE - 1) / TILE, (R + TILE - 1) / TILE);
             const double K = st.b - st.a, N = st.c - st.b;
             SLK_RUN("gptq_trailing", 2.0 * R * K * N, 4.0 * R * K + 8.0 * K * N + 8.0 * R * N, s,
-                    k_gptq_trailing<<<grid, 256, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, st.b, st.c));
+                    k_gptq_trailing<<<grid, 256, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, st.b, st.c,
+                                                          n % 4 == 0 && st.a % 4 == 0 && st.b % 2 == 0 && (uintptr_t)U % 16 == 0));
         }
     }
     SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, Q, idx));

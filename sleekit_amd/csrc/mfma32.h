@@ -6,7 +6,19 @@
 //   K is consumed in steps of 16 staged through LDS as As[k][row], Bs[k][col] with a
 //   pitch of 132 floats, register-prefetching the next step during the MFMAs.
 //
-// Operand maps (guide section 3):
+// Operands come from FRAGMENT LOADERS: la(k0, ra) / lb(k0, rb) fill the 8 floats this
+// thread stages per K-step.  Loaders are written per kernel so that interior tiles use
+// unconditional 16-byte loads; a guard expressed as `cond ? load : 0` per element makes
+// hipcc branch around every load and wait for each one (guide section 5, trap (c)), which is
+// what held the first version of these kernels at a quarter of the MFMA rate.
+//
+// Thread -> staged elements (t = threadIdx.x):
+//   A, K contiguous in memory : row  t >> 1,        k = k0 + (t & 1) * 8 + e
+//   A, rows contiguous        : rows (t & 15) * 8 + e,  k = k0 + (t >> 4)
+//   B, columns contiguous     : k = k0 + (t >> 4),  cols (t & 15) * 8 + e
+//   B, K contiguous           : col  t >> 1,        k = k0 + (t & 1) * 8 + e
+//
+// MFMA operand maps (guide section 3):
 //   A: lane l holds A[row = l & 31][k = l >> 5]      B: lane l holds B[k = l >> 5][col = l & 31]
 //   D: register r of lane l is D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]
 #pragma once
@@ -16,6 +28,7 @@
 namespace slk {
 
 typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
 
 constexpr int T32 = 128;        // output tile edge
 constexpr int K32 = 16;         // K depth per LDS round
@@ -38,13 +51,35 @@ struct Acc128 {
     }
 };
 
+// 8 consecutive floats from p (16-byte aligned when VEC), as two 16-byte loads.
+template <bool VEC>
+__device__ __forceinline__ void load8(const float *p, float (&v)[8]) {
+    if (VEC) {
+        const float4_t lo = *reinterpret_cast<const float4_t *>(p), hi = *reinterpret_cast<const float4_t *>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = lo[e];
+            v[4 + e] = hi[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p[e];
+    }
+}
+
+// Edge-safe version: element e is taken from p[min(e, last)] and zeroed by a MULTIPLY when
+// e > last or !row_ok (a multiply cannot be turned back into a branch around the load).
+__device__ __forceinline__ void load8_guarded(const float *p, int last, bool row_ok, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ee = min(e, max(last, 0));
+        v[e] = p[ee] * ((row_ok && e <= last) ? 1.0f : 0.0f);
+    }
+}
+
 // acc += A(128 x K) * B(K x 128) for k in [k_begin, k_end), a multiple of K32 deep.
-// fa(r, k), fb(k, c): operand elements for tile-local r, c and absolute k.
-// Each thread stages 8 elements per operand per step:
-//   A_K_FAST : rows t >> 1, k-octet (t & 1) * 8          else: k = t >> 4, rows (t & 15) * 8 ..+7
-//   B_C_FAST : k = t >> 4, cols (t & 15) * 8 ..+7         else: cols t >> 1, k-octet (t & 1) * 8
-template <bool A_K_FAST, bool B_C_FAST, class FA, class FB>
-__device__ __forceinline__ void tile128_mac(Acc128 &acc, Tile128Smem &sm, int k_begin, int k_end, FA fa, FB fb) {
+template <bool A_K_FAST, bool B_C_FAST, class LA, class LB>
+__device__ __forceinline__ void tile128_mac(Acc128 &acc, Tile128Smem &sm, int k_begin, int k_end, LA la, LB lb) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -54,13 +89,6 @@ __device__ __forceinline__ void tile128_mac(Acc128 &acc, Tile128Smem &sm, int k_
     const int b_c = B_C_FAST ? ((t & 15) * 8) : (t >> 1);
     const int b_k = B_C_FAST ? (t >> 4) : ((t & 1) * 8);
 
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            ra[e] = A_K_FAST ? fa(a_r, k0 + a_k + e) : fa(a_r + e, k0 + a_k);
-            rb[e] = B_C_FAST ? fb(k0 + b_k, b_c + e) : fb(k0 + b_k + e, b_c);
-        }
-    };
     auto stash = [&]() {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -70,12 +98,16 @@ __device__ __forceinline__ void tile128_mac(Acc128 &acc, Tile128Smem &sm, int k_
     };
 
     if (k_begin >= k_end) return;
-    fetch(k_begin);
+    la(k_begin, ra);
+    lb(k_begin, rb);
     for (int k0 = k_begin; k0 < k_end; k0 += K32) {
         __syncthreads();
         stash();
         __syncthreads();
-        if (k0 + K32 < k_end) fetch(k0 + K32);
+        if (k0 + K32 < k_end) {
+            la(k0 + K32, ra);
+            lb(k0 + K32, rb);
+        }
 #pragma unroll
         for (int kk = 0; kk < K32; kk += 2) {
             const int kr = kk + (lane >> 5);

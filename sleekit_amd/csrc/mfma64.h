@@ -1,17 +1,25 @@
-// float64 MFMA tile core for gfx950: one 256-thread workgroup (4 waves, one per
-// SIMD) accumulates a 64 x 64 output tile with v_mfma_f64_16x16x4_f64.
+// float64 MFMA tile core for gfx950: one 256-thread workgroup (4 waves, one per SIMD)
+// accumulates a 64 x 64 output tile with v_mfma_f64_16x16x4_f64.
 //
 //   wave w owns the 32 x 32 sub-tile (w >> 1, w & 1): 2 x 2 MFMA blocks of 16 x 16.
-//   K is consumed in steps of 16 staged through LDS: As[k][row], Bs[k][col]
-//   with a row pitch of 80 doubles (== 16 mod 32): the two 16-lane groups that a
-//   32-lane half of ds_read_b64 serves then fall on disjoint bank ranges.
-//   Global loads of step s+1 are issued into registers before the MFMAs of
-//   step s and written to LDS after them (register double buffering).
+//   K is consumed in steps of 32 staged through LDS.  A is staged row-major
+//   As[row][k] with a pitch of 34 doubles: a thread's 8 consecutive k go down as four
+//   ds_write_b128, and the MFMA operand read (lane l: row l & 15, k l >> 4) walks banks
+//   4 row + 2 k, conflict-free for a 32-lane half.  B is staged either the same way
+//   (operand given as [col][k]) or as Bs[k][col] with a pitch of 80 (operand given as [k][col]).
+//   Global loads of step s+1 are issued before the MFMAs of step s (register double buffer).
 //
-// Operand maps of v_mfma_f64_16x16x4_f64 (guide section 3, checked by
-// tests/test_gpu_kernels.py::test_dgemm_tile_asymmetric):
-//   A: lane l holds A[row = l & 15][k = l >> 4]
-//   B: lane l holds B[k = l >> 4][col = l & 15]
+// Operands come from FRAGMENT LOADERS la(k0, v) / lb(k0, v) that fill this thread's 8
+// doubles per K-step; kernels write them so interior tiles use unconditional 16-byte loads
+// (see mfma32.h for why per-element guards are poison).
+//
+// Thread -> staged elements (t = threadIdx.x):
+//   A and K-contiguous B : row/col t >> 2,     k = k0 + (t & 3) * 8 + e
+//   column-contiguous B  : k = k0 + (t >> 3),  cols (t & 7) * 8 + e
+//
+// Operand maps of v_mfma_f64_16x16x4_f64 (guide section 3; exercised with asymmetric data by
+// tests/test_gpu_parity.py::test_factor_of_plain_matrix_and_not_pd):
+//   A: lane l holds A[row = l & 15][k = l >> 4]     B: lane l holds B[k = l >> 4][col = l & 15]
 //   D: register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15]
 #pragma once
 
@@ -20,14 +28,17 @@
 namespace slk {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef float float4v_t __attribute__((ext_vector_type(4)));
 
 constexpr int TILE = 64;       // output tile edge
-constexpr int KSTEP = 16;      // K depth staged per LDS round
-constexpr int LDS_PITCH = 80;  // doubles per staged k-row
+constexpr int KSTEP = 32;      // K depth staged per LDS round
+constexpr int PITCH_RK = 34;   // [row][k] images
+constexpr int PITCH_KC = 80;   // [k][col] image
 
 struct Tile64Smem {
-    double a[KSTEP][LDS_PITCH];
-    double b[KSTEP][LDS_PITCH];
+    double a[TILE * PITCH_RK];
+    double b[KSTEP * PITCH_KC];  // >= TILE * PITCH_RK
 };
 
 struct Acc64 {
@@ -40,52 +51,85 @@ struct Acc64 {
     }
 };
 
-// Accumulate acc += A(64 x K) * B(K x 64) for k in [k_begin, k_end), k_end - k_begin a
-// multiple of KSTEP.  `fa(r, k)` / `fb(k, c)` return operand elements as double for
-// tile-local r, c in [0, 64) and absolute k.  A_K_FAST / B_C_FAST say which index is
-// contiguous in the operand's memory so the staging loads coalesce.
-template <bool A_K_FAST, bool B_C_FAST, class FA, class FB>
-__device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_begin, int k_end, FA fa, FB fb) {
+// 8 consecutive doubles (16-byte aligned when VEC) as four 16-byte loads.
+template <bool VEC>
+__device__ __forceinline__ void load8d(const double *p, double (&v)[8]) {
+    if (VEC) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const double2_t x = *reinterpret_cast<const double2_t *>(p + 2 * h);
+            v[2 * h] = x[0];
+            v[2 * h + 1] = x[1];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p[e];
+    }
+}
+
+// Edge-safe: element e from p[min(e, last)], zeroed by a multiply when e > last or !ok.
+__device__ __forceinline__ void load8d_guarded(const double *p, int last, bool ok, double (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = p[min(e, max(last, 0))] * ((ok && e <= last) ? 1.0 : 0.0);
+}
+
+// 8 consecutive floats widened to double.
+template <bool VEC>
+__device__ __forceinline__ void load8f_as_d(const float *p, double (&v)[8]) {
+    if (VEC) {
+        const float4v_t lo = *reinterpret_cast<const float4v_t *>(p), hi = *reinterpret_cast<const float4v_t *>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (double)lo[e];
+            v[4 + e] = (double)hi[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (double)p[e];
+    }
+}
+__device__ __forceinline__ void load8f_as_d_guarded(const float *p, int last, bool ok, double (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (double)p[min(e, max(last, 0))] * ((ok && e <= last) ? 1.0 : 0.0);
+}
+
+// acc += A(64 x K) * B(K x 64) for k in [k_begin, k_end), k_end - k_begin a multiple of KSTEP.
+template <bool B_C_FAST, class LA, class LB>
+__device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_begin, int k_end, LA la, LB lb) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    double ra[4], rb[4];
+    double ra[8], rb[8];
+    double *a_dst = sm.a + (t >> 2) * PITCH_RK + (t & 3) * 8;
+    double *b_dst = B_C_FAST ? sm.b + (t >> 3) * PITCH_KC + (t & 7) * 8 : sm.b + (t >> 2) * PITCH_RK + (t & 3) * 8;
 
-    // staging coordinates of this thread's 4 elements
-    const int a_r = A_K_FAST ? (t >> 2) : ((t & 15) * 4);
-    const int a_k = A_K_FAST ? ((t & 3) * 4) : (t >> 4);
-    const int b_c = B_C_FAST ? ((t & 15) * 4) : (t >> 2);
-    const int b_k = B_C_FAST ? (t >> 4) : ((t & 3) * 4);
-
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ra[e] = A_K_FAST ? fa(a_r, k0 + a_k + e) : fa(a_r + e, k0 + a_k);
-            rb[e] = B_C_FAST ? fb(k0 + b_k, b_c + e) : fb(k0 + b_k + e, b_c);
-        }
-    };
     auto stash = [&]() {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (A_K_FAST) sm.a[a_k + e][a_r] = ra[e]; else sm.a[a_k][a_r + e] = ra[e];
-            if (B_C_FAST) sm.b[b_k][b_c + e] = rb[e]; else sm.b[b_k + e][b_c] = rb[e];
+        for (int h = 0; h < 4; ++h) {
+            *reinterpret_cast<double2_t *>(a_dst + 2 * h) = (double2_t){ra[2 * h], ra[2 * h + 1]};
+            *reinterpret_cast<double2_t *>(b_dst + 2 * h) = (double2_t){rb[2 * h], rb[2 * h + 1]};
         }
     };
 
     if (k_begin >= k_end) return;
-    fetch(k_begin);
+    la(k_begin, ra);
+    lb(k_begin, rb);
+    const double *a_src = sm.a + (wr * 32 + (lane & 15)) * PITCH_RK + (lane >> 4);
+    const double *b_src = B_C_FAST ? sm.b + (lane >> 4) * PITCH_KC + wc * 32 + (lane & 15)
+                                   : sm.b + (wc * 32 + (lane & 15)) * PITCH_RK + (lane >> 4);
     for (int k0 = k_begin; k0 < k_end; k0 += KSTEP) {
         __syncthreads();  // previous step's LDS reads are done
         stash();
         __syncthreads();
-        if (k0 + KSTEP < k_end) fetch(k0 + KSTEP);
+        if (k0 + KSTEP < k_end) {
+            la(k0 + KSTEP, ra);
+            lb(k0 + KSTEP, rb);
+        }
 #pragma unroll
         for (int kk = 0; kk < KSTEP; kk += 4) {
-            const int kr = kk + (lane >> 4);
-            const double a0 = sm.a[kr][wr * 32 + (lane & 15)];
-            const double a1 = sm.a[kr][wr * 32 + 16 + (lane & 15)];
-            const double b0 = sm.b[kr][wc * 32 + (lane & 15)];
-            const double b1 = sm.b[kr][wc * 32 + 16 + (lane & 15)];
+            const double a0 = a_src[kk], a1 = a_src[16 * PITCH_RK + kk];
+            const double b0 = B_C_FAST ? b_src[kk * PITCH_KC] : b_src[kk];
+            const double b1 = B_C_FAST ? b_src[kk * PITCH_KC + 16] : b_src[16 * PITCH_RK + kk];
             acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.c[0][0], 0, 0, 0);
             acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.c[0][1], 0, 0, 0);
             acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.c[1][0], 0, 0, 0);

@@ -142,27 +142,33 @@ __device__ __forceinline__ long long total_order_key(double k) {
     return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFLL);
 }
 
-__global__ __launch_bounds__(256) void k_rank_order(const double *__restrict__ keys, int n, int identity,
-                                                    long long *__restrict__ order) {
+// grid (n / 256, SLICES): block (bx, by) counts, for its 256 keys, the smaller keys inside j-slice by
+// and adds the partial rank atomically (integer adds: order-independent, deterministic).
+__global__ __launch_bounds__(256) void k_rank_partial(const double *__restrict__ keys, int n, int slice,
+                                                      int *__restrict__ rank) {
     __shared__ long long tile[1024];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (identity) {
-        if (i < n) order[i] = i;
-        return;
-    }
     const long long ki = i < n ? total_order_key(keys[i]) : 0;
-    int rank = 0;
-    for (int base = 0; base < n; base += 1024) {
-        const int m = min(1024, n - base);
+    const int j_lo = blockIdx.y * slice, j_hi = min(n, j_lo + slice);
+    int count = 0;
+    for (int base = j_lo; base < j_hi; base += 1024) {
+        const int m = min(1024, j_hi - base);
         __syncthreads();
         for (int t = threadIdx.x; t < m; t += blockDim.x) tile[t] = total_order_key(keys[base + t]);
         __syncthreads();
         for (int t = 0; t < m; ++t) {
             const long long kj = tile[t];
-            rank += (kj < ki) || (kj == ki && (base + t) < i);
+            // bitwise, not short-circuit: a taken branch costs ~45 cycles here
+            count += (int)(kj < ki) | ((int)(kj == ki) & (int)(base + t < i));
         }
     }
-    if (i < n) order[rank] = i;
+    if (i < n && count) atomicAdd(&rank[i], count);
+}
+
+__global__ __launch_bounds__(256) void k_rank_scatter(const int *__restrict__ rank, int n, int identity,
+                                                      long long *__restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[identity ? i : rank[i]] = i;
 }
 
 // ------------------------------------------------------------------ gather
@@ -240,7 +246,8 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
     Arena ws(workspace, ws_bytes);
     float *scal = ws.take<float>(64);
     double *keys = ws.take<double>((size_t)n);
-    if (!scal || !keys) {
+    int *rank = ws.take<int>((size_t)n);
+    if (!scal || !keys || !rank) {
         set_error("workspace too small");
         return SLK_E_WS;
     }
@@ -249,7 +256,13 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
     SLK_RUN("diag_mean", 0, 4.0 * n, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
     SLK_RUN("order_keys", 0, 12.0 * n, s,
             k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, order_mode >= SLK_ORDER_ERR ? miss : nullptr, scal, keys));
-    SLK_RUN("rank_order", 0, 16.0 * n, s, k_rank_order<<<(n + 255) / 256, 256, 0, s>>>(keys, n, order_mode == SLK_ORDER_NONE, order_out));
+    const int identity = order_mode == SLK_ORDER_NONE;
+    if (!identity) {
+        SLK_HIP(hipMemsetAsync(rank, 0, sizeof(int) * (size_t)n, s));
+        const int slices = 16, slice = (n + slices - 1) / slices;
+        SLK_RUN("rank_partial", 0, 16.0 * n, s, k_rank_partial<<<dim3((n + 255) / 256, slices), 256, 0, s>>>(keys, n, slice, rank));
+    }
+    SLK_RUN("rank_scatter", 0, 12.0 * n, s, k_rank_scatter<<<(n + 255) / 256, 256, 0, s>>>(rank, n, identity, order_out));
     SLK_RUN("gather_reversed", 0, 2.0 * n * n + 8.0 * ld * ld, s,
             k_gather_reversed<<<ld < 2048 ? ld : 2048, 256, 0, s>>>(H, n, ld, order_out, scal, A));
     return SLK_OK;

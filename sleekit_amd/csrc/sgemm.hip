@@ -14,20 +14,48 @@ namespace slk {
 __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W, const float *__restrict__ Q,
                                                      const float *__restrict__ H, int R, int n,
                                                      float *__restrict__ G, float *__restrict__ partial,
-                                                     int n_tiles) {
+                                                     int n_tiles, int vec_ok) {
     __shared__ Tile128Smem sm;
     __shared__ float rowpart[2][T32];
     const int r0 = blockIdx.y * T32, j0 = blockIdx.x * T32;
+    const int t = threadIdx.x;
     Acc128 acc;
     acc.zero();
     const int kend = (n + K32 - 1) / K32 * K32;
-    tile128_mac<true, true>(
-        acc, sm, 0, kend,
-        [&](int r, int k) {
-            const size_t o = (size_t)(r0 + r) * n + k;
-            return (r0 + r < R && k < n) ? W[o] - Q[o] : 0.0f;
-        },
-        [&](int k, int c) { return (k < n && j0 + c < n) ? H[(size_t)k * n + j0 + c] : 0.0f; });
+    const int a_row = r0 + (t >> 1), a_k = (t & 1) * 8;  // A: D = W - Q, K contiguous
+    const int b_k = t >> 4, b_col = j0 + (t & 15) * 8;   // B: H, columns contiguous
+    if (vec_ok && r0 + T32 <= R && j0 + T32 <= n && kend == n) {
+        // interior tile: unconditional 16-byte loads
+        const float *pw = W + (size_t)a_row * n + a_k, *pq = Q + (size_t)a_row * n + a_k;
+        const float *ph = H + (size_t)b_k * n + b_col;
+        tile128_mac<true, true>(
+            acc, sm, 0, kend,
+            [&](int k0, float(&v)[8]) {
+                float w[8], q[8];
+                load8<true>(pw + k0, w);
+                load8<true>(pq + k0, q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = w[e] - q[e];
+            },
+            [&](int k0, float(&v)[8]) { load8<true>(ph + (size_t)k0 * n, v); });
+    } else {
+        const bool row_ok = a_row < R;
+        const size_t arow = (size_t)min(a_row, R - 1) * n;
+        tile128_mac<true, true>(
+            acc, sm, 0, kend,
+            [&](int k0, float(&v)[8]) {
+                const int k = min(k0 + a_k, n - 1), last = n - 1 - (k0 + a_k);
+                float w[8], q[8];
+                load8_guarded(W + arow + k, last, row_ok, w);
+                load8_guarded(Q + arow + k, last, row_ok, q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = w[e] - q[e];
+            },
+            [&](int k0, float(&v)[8]) {
+                const int k = k0 + b_k;
+                load8_guarded(H + (size_t)min(k, n - 1) * n + min(b_col, n - 1), n - 1 - b_col, k < n, v);
+            });
+    }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -70,17 +98,34 @@ __global__ __launch_bounds__(256) void k_error_reduce(const float *__restrict__ 
 // ------------------------------------------------------------------ Hessian accumulation
 // Lower tiles of X^T X, mirrored on store so H stays exactly symmetric.
 __global__ __launch_bounds__(256) void k_hessian_tiles(float *__restrict__ H, const float *__restrict__ X, int n, int T,
-                                                       float factor, float count) {
+                                                       float factor, float count, int vec_ok) {
     __shared__ Tile128Smem sm;
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj > bi) return;
     const int i0 = bi * T32, j0 = bj * T32;
+    const int t = threadIdx.x;
     Acc128 acc;
     acc.zero();
     const int kend = (T + K32 - 1) / K32 * K32;
-    tile128_mac<false, true>(
-        acc, sm, 0, kend, [&](int r, int k) { return (i0 + r < n && k < T) ? X[(size_t)k * n + i0 + r] : 0.0f; },
-        [&](int k, int c) { return (k < T && j0 + c < n) ? X[(size_t)k * n + j0 + c] : 0.0f; });
+    // both operands are rows of X (tokens x features): A[r][k] = X[k][i0 + r], B[k][c] = X[k][j0 + c]
+    const int x_k = t >> 4, a_col = i0 + (t & 15) * 8, b_col = j0 + (t & 15) * 8;
+    if (vec_ok && i0 + T32 <= n && kend == T) {  // j0 <= i0, so the B tile is interior too
+        const float *pa = X + (size_t)x_k * n + a_col, *pb = X + (size_t)x_k * n + b_col;
+        tile128_mac<false, true>(
+            acc, sm, 0, kend, [&](int k0, float(&v)[8]) { load8<true>(pa + (size_t)k0 * n, v); },
+            [&](int k0, float(&v)[8]) { load8<true>(pb + (size_t)k0 * n, v); });
+    } else {
+        tile128_mac<false, true>(
+            acc, sm, 0, kend,
+            [&](int k0, float(&v)[8]) {
+                const int k = k0 + x_k;
+                load8_guarded(X + (size_t)min(k, T - 1) * n + min(a_col, n - 1), n - 1 - a_col, k < T, v);
+            },
+            [&](int k0, float(&v)[8]) {
+                const int k = k0 + x_k;
+                load8_guarded(X + (size_t)min(k, T - 1) * n + min(b_col, n - 1), n - 1 - b_col, k < T, v);
+            });
+    }
     tile128_foreach(acc, [&](int r, int c, float v) {
         const int i = i0 + r, j = j0 + c;
         if (i < n && j < n && (bi != bj || j <= i)) {
@@ -118,8 +163,9 @@ int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n,
     }
     hipStream_t s = as_stream(stream);
     dim3 grid(n_tiles, (R + T32 - 1) / T32);
+    const int vec_ok = n % 4 == 0 && ((uintptr_t)W | (uintptr_t)Q | (uintptr_t)H) % 16 == 0;
     SLK_RUN("error_gemm", 2.0 * R * n * n, 8.0 * R * n + 4.0 * n * n + (G ? 4.0 * R * n : 0.0), s,
-            k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles));
+            k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles, vec_ok));
     SLK_RUN("error_reduce", 0, 4.0 * R * n_tiles, s, k_error_reduce<<<(R + 255) / 256, 256, 0, s>>>(partial, R, n_tiles, row_err));
     return SLK_OK;
 }
@@ -135,7 +181,7 @@ int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, 
     SLK_RUN("mean_update", 0, 4.0 * T * n, s, k_mean_update<<<(n + 255) / 256, 256, 0, s>>>(mean, X, n, T, factor, count));
     dim3 grid(nt, nt);
     SLK_RUN("hessian_syrk", (double)T * n * (n + 1), 4.0 * T * n + 8.0 * n * n, s,
-            k_hessian_tiles<<<grid, 256, 0, s>>>(H, X, n, T, factor, count));
+            k_hessian_tiles<<<grid, 256, 0, s>>>(H, X, n, T, factor, count, n % 4 == 0 && (uintptr_t)X % 16 == 0));
     return SLK_OK;
 }
 

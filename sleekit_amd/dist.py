@@ -39,16 +39,20 @@ def factor_root(layer_index, size):
 class HipBackend:
     """The real thing: sleekit_amd.engine on the current device."""
 
-    def __init__(self, quantizer, act_order="diag", damp=0.01, nb_ls_moves=0, with_error=True):
+    def __init__(self, quantizer, act_order="diag", damp=0.01, nb_ls_moves=0, with_error=True, overlap=True):
         from . import engine
 
-        self.engine, self.quantizer = engine, quantizer
+        self.engine, self.quantizer, self.overlap = engine, quantizer, overlap
         self.act_order, self.damp, self.moves, self.with_error = act_order, damp, nb_ls_moves, with_error
 
     def streams(self):
-        """(factor stream, comm stream), created once per backend."""
+        """(factor streams, comm stream, loop streams), created once; (None, None, None) = everything in order."""
+        if not self.overlap:
+            return None, None, None
         if not hasattr(self, "_streams"):
-            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            nf, nl = (self.overlap if isinstance(self.overlap, tuple) else (2, 2))
+            self._streams = ([torch.cuda.Stream() for _ in range(nf)], torch.cuda.Stream(),
+                             [torch.cuda.Stream() for _ in range(nl)])
         return self._streams
 
     def alloc_factor(self, n, device):
@@ -103,25 +107,30 @@ def quantize_stream(layers, backend, comm_device=None):
     n_layers = len(layers)
     factors = [None] * n_layers
     ready = [None] * n_layers
-    fstream, cstream = backend.streams() if hasattr(backend, "streams") else (None, None)
+    fstreams, cstream, lstreams = backend.streams() if hasattr(backend, "streams") else (None, None, None)
+    side = fstreams is not None
+    here = torch.cuda.current_stream() if side else None
 
     def on(stream):
         return torch.cuda.stream(stream) if stream is not None else _NullCtx()
 
-    # 1. every rank factors the layers it is the root of (concurrently across ranks)
-    if fstream is not None:
-        fstream.wait_stream(torch.cuda.current_stream())
-    with on(fstream):
-        for l in range(rank, n_layers, size):
+    # 1. every rank factors the layers it is the root of (concurrently across ranks); the
+    #    factorisations are latency-bound chains, so consecutive ones alternate between streams
+    mine = list(range(rank, n_layers, size))
+    for k, l in enumerate(mine):
+        fs = fstreams[k % len(fstreams)] if side else None
+        if side and k < len(fstreams):
+            fs.wait_stream(here)
+        with on(fs):
             factors[l] = backend.factorize(layers[l])
-            if fstream is not None:
+            if side:
                 ready[l] = torch.cuda.Event()
-                ready[l].record(fstream)
+                ready[l].record(fs)
     # 2. one asynchronous broadcast per layer from its root, issued in layer order
     pending = [None] * n_layers
     if size > 1:
         if cstream is not None:
-            cstream.wait_stream(torch.cuda.current_stream())
+            cstream.wait_stream(here)
         with on(cstream):
             for l in range(n_layers):
                 root = factor_root(l, size)
@@ -131,23 +140,34 @@ def quantize_stream(layers, backend, comm_device=None):
                 elif ready[l] is not None:
                     cstream.wait_event(ready[l])
                 pending[l] = [dist.broadcast(t, src=root, async_op=True) for t in factors[l]]
-    # 3. every rank runs its rows of every layer as the factors land
+    # 3. every rank runs its rows of every layer as the factors land (loops of consecutive layers
+    #    alternate between streams too: their leaf chains are latency-bound as well)
     out = []
     for l, layer in enumerate(layers):
-        if pending[l] is not None:
-            for work in pending[l]:
-                work.wait()  # orders the current stream behind the transfer; no host block on GPU
-        elif ready[l] is not None:
-            torch.cuda.current_stream().wait_event(ready[l])
-        lo, hi = row_range(layer["W"].shape[0], rank, size)
-        shard = backend.run_rows(layer, lo, hi, factors[l])
+        ls = lstreams[l % len(lstreams)] if side else None
+        if side and l < len(lstreams):
+            ls.wait_stream(here)
+        with on(ls):
+            if pending[l] is not None:
+                for work in pending[l]:
+                    work.wait()  # orders the stream behind the transfer; no host block on GPU
+            elif ready[l] is not None:
+                ls.wait_event(ready[l])
+            lo, hi = row_range(layer["W"].shape[0], rank, size)
+            shard = backend.run_rows(layer, lo, hi, factors[l])
         shard["info"] = factors[l][2]
         out.append(shard)
-    if fstream is not None:
-        # tensors made on the side streams are consumed on the main stream: keep the allocator honest
+    if side:
+        for st in lstreams:
+            here.wait_stream(st)
+        # tensors made on the side streams are consumed on the caller's stream: keep the allocator honest
         for f in factors:
             for t in f:
-                t.record_stream(torch.cuda.current_stream())
+                t.record_stream(here)
+        for shard in out:
+            for t in shard.values():
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(here)
     return out
 
 

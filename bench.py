@@ -39,7 +39,7 @@ import torch.distributed as dist
 # vector = matrix = 78.6 TFLOP/s, i.e. 32 flop/clk/SIMD at 2.4 GHz on 1024 SIMDs)
 PEAK = {"hbm": (8.0e12, "GB/s"), "mfma_f64": (78.6e12, "TFLOP/s"), "mfma_f32": (157.3e12, "TFLOP/s")}
 KERNEL_DTYPE = {
-    "chol_panel": "mfma_f64", "chol_syrk": "mfma_f64", "trtri_stage0": "mfma_f64", "trtri_stage1": "mfma_f64",
+    "chol_panel": "mfma_f64", "chol_syrk_inner": "mfma_f64", "chol_syrk_outer": "mfma_f64", "trtri_stage0": "mfma_f64", "trtri_stage1": "mfma_f64",
     "gptq_window": "mfma_f64", "gptq_window_wide": "mfma_f64", "gptq_trailing": "mfma_f64",
     "error_gemm": "mfma_f32", "hessian_syrk": "mfma_f32",
 }

@@ -183,13 +183,22 @@ __global__ __launch_bounds__(256) void k_syrk_tiles(double *__restrict__ A, int 
 // Level s of the inverse: nodes [lo, lo + s) u [lo + s, min(lo + 2s, nt)), lo a multiple of 2s.
 // STAGE 0:  S[bi][bj] =  sum_{kt = bj .. mid-1} L[bi][kt] X[kt][bj]
 // STAGE 1:  X[bi][bj] = -sum_{kt = mid .. bi}   X[bi][kt] S[kt][bj]
+// Tiles of one level have K depths from 1 to s tiles; with all of them resident at once the
+// level lasts as long as the CU that drew the deepest ones.  Blocks are therefore numbered
+// deepest-first (stage 0: by column inside the node, stage 1: by row from the bottom), so the
+// blocks id, id + 256, ... that land on one CU mix depths.
 template <int STAGE>
 __global__ __launch_bounds__(256) void k_trtri_level(const double *__restrict__ L, double *__restrict__ X,
                                                      double *__restrict__ S, int ld, int nt, int s) {
     __shared__ __attribute__((aligned(16))) Tile64Smem sm;
-    const int bi = blockIdx.y, bj = blockIdx.x;
-    const int lo = bi / (2 * s) * (2 * s), mid = lo + s;
-    if (bi < mid || bj < lo || bj >= mid) return;
+    // block id -> (node, slow, fast): `fast` runs over the s tiles of the balanced direction
+    const int id = blockIdx.x;
+    const int per_node = s * s, node = id / per_node, in_node = id % per_node;
+    const int deep = in_node / s, other = in_node % s;  // deep = 0 is the deepest K range
+    const int lo = node * 2 * s, mid = lo + s;
+    const int bi = (STAGE == 0) ? mid + other : mid + (s - 1 - deep);
+    const int bj = (STAGE == 0) ? lo + deep : lo + other;
+    if (bi >= nt) return;
     Acc64 acc;
     acc.zero();
     const int t = threadIdx.x;
@@ -262,7 +271,7 @@ extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, vo
                 dim3 grid(tj1 - tj0, nt - tj0);
                 double tiles = 0;
                 for (int bj = tj0; bj < tj1; ++bj) tiles += nt - bj;
-                SLK_RUN("chol_syrk", tiles * 2.0 * 64 * 64 * PANEL, 8.0 * (ld - k0) * PANEL + tiles * 16.0 * 64 * 64, s,
+                SLK_RUN("chol_syrk_inner", tiles * 2.0 * 64 * 64 * PANEL, 8.0 * (ld - k0) * PANEL + tiles * 16.0 * 64 * 64, s,
                         k_syrk_tiles<<<grid, 256, 0, s>>>(A, ld, tj0, tj0, k0, k0 + PANEL));
             }
         }
@@ -270,12 +279,13 @@ extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, vo
         if (nt > t0) {
             dim3 grid(nt - t0, nt - t0);
             const double tiles = 0.5 * (nt - t0) * (nt - t0 + 1);
-            SLK_RUN("chol_syrk", tiles * 2.0 * 64 * 64 * (K1 - K0), 8.0 * (ld - K1) * (K1 - K0) + tiles * 16.0 * 64 * 64, s,
+            SLK_RUN("chol_syrk_outer", tiles * 2.0 * 64 * 64 * (K1 - K0), 8.0 * (ld - K1) * (K1 - K0) + tiles * 16.0 * 64 * 64, s,
                     k_syrk_tiles<<<grid, 256, 0, s>>>(A, ld, t0, t0, K0, K1));
         }
     }
     for (int lvl = 1; lvl < nt; lvl *= 2) {
-        dim3 grid(nt, nt);
+        const int nodes = (nt + 2 * lvl - 1) / (2 * lvl);
+        dim3 grid(nodes * lvl * lvl);
         // work of this level: for every node, tiles (bi in B, bj in A) with their triangular K ranges
         double f0 = 0, f1 = 0, tiles = 0;
         for (int lo = 0; lo + lvl < nt; lo += 2 * lvl) {

@@ -445,11 +445,13 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
                                                                            tab));
             }
         } else {
-            dim3 grid((st.c - st.b + TILE - 1) / TILE, (R + TILE - 1) / TILE);
             const double K = st.b - st.a, N = st.c - st.b;
-            SLK_RUN("gptq_trailing", 2.0 * R * K * N, 4.0 * R * K + 8.0 * K * N + 8.0 * R * N, s,
-                    k_gptq_trailing<<<grid, 256, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, st.b, st.c,
-                                                          n % 4 == 0 && st.a % 4 == 0 && st.b % 2 == 0 && (uintptr_t)U % 16 == 0));
+            const int vec_ok = n % 4 == 0 && st.a % 4 == 0 && st.b % 2 == 0 && (uintptr_t)U % 16 == 0;
+            {
+                dim3 grid((st.c - st.b + TILE - 1) / TILE, (R + TILE - 1) / TILE);
+                SLK_RUN("gptq_trailing", 2.0 * R * K * N, 4.0 * R * K + 8.0 * K * N + 8.0 * R * N, s,
+                        k_gptq_trailing<<<grid, 256, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, st.b, st.c, vec_ok));
+            }
         }
     }
     SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, Q, idx));

@@ -138,6 +138,11 @@ __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_beg
     }
 }
 
+// A 128 x 128 variant (64 accumulator doubles per lane, one wave per SIMD) was measured
+// SLOWER (33 vs 49 TFLOP/s on the trailing update): the float64 MFMA pipe of this chip only
+// saturates with >= 4 waves per SIMD (tools/micro_mfma.py: 32 TFLOP/s at one wave per SIMD,
+// 49 at eight), so small tiles at high occupancy win.
+
 // Visit every accumulator element of this thread: f(row, col, value), tile-local coordinates.
 template <class F>
 __device__ __forceinline__ void tile64_foreach(const Acc64 &acc, F f) {

@@ -97,4 +97,12 @@ __device__ __forceinline__ float grid_value(float x, const Grid g) {
     return grid_val(grid_pos(x, g, 0.0f, 0.0f, g.top), g);
 }
 
+// Broadcast lane `src` (wave-uniform index) of a double to the whole wave through SGPRs.
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 }  // namespace slk

@@ -22,14 +22,13 @@ namespace slk {
 
 constexpr int PANEL = 64;
 constexpr int OUTER = 256;
-constexpr int DP = 65;  // pitch of the 64 x 64 LDS tiles (odd: column walks are conflict-free)
+
+constexpr int TP = 66;  // pitch of the 64 x 64 LDS tiles: MFMA operand reads walk banks 4 row + 2 k
 
 struct PanelSmem {
-    double d[PANEL][DP];      // staging of the diagonal tile, then L11
-    double x[PANEL][DP];      // inv(L11)
-    double col[2][4][PANEL];  // column j as seen by each wave (only the owner's slot is read)
-    double row[2][2 * PANEL]; // row tt of the inverse being propagated, wave-major (+ a dump area)
-    double rdiag[PANEL];      // 1 / L11[j][j]
+    double t[PANEL][TP];  // diagonal tile -> L11 (lower)
+    double x[PANEL][TP];  // inv(L11)
+    double rdiag[PANEL];  // 1 / L11[j][j]
     Tile64Smem mm;
 };
 
@@ -44,104 +43,153 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
     return y;
 }
 
+// ---- 16 x 16 block helpers on v_mfma_f64_16x16x4_f64; operands straight from LDS ----------
+// "A pattern": lane l reads M[row = l & 15][4 g + (l >> 4)] of a row-major block, which serves both
+// as the A operand of M and as the B operand of M^T.
+__device__ __forceinline__ double4_t blk_load_d(const double *blk, int lane) {  // D layout: reg r = [ (l>>4) + 4r ][ l & 15 ]
+    double4_t c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = blk[((lane >> 4) + 4 * r) * TP + (lane & 15)];
+    return c;
+}
+__device__ __forceinline__ void blk_store_d(double *blk, int lane, double4_t c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) blk[((lane >> 4) + 4 * r) * TP + (lane & 15)] = c[r];
+}
+// acc += sign * A * Bt^T, both 16 x 16 row-major blocks in LDS
+__device__ __forceinline__ double4_t blk_mma_abt(const double *a, const double *bt, double4_t acc, double sign, int lane) {
+    const int o = (lane & 15) * TP + (lane >> 4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * a[o + 4 * g], bt[o + 4 * g], acc, 0, 0, 0);
+    return acc;
+}
+// acc += A * B, B row-major [k][col] in LDS
+__device__ __forceinline__ double4_t blk_mma_ab(const double *a, const double *b, double4_t acc, int lane) {
+    const int oa = (lane & 15) * TP + (lane >> 4), ob = (lane >> 4) * TP + (lane & 15);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[oa + 4 * g], b[ob + 4 * g * TP], acc, 0, 0, 0);
+    return acc;
+}
+// acc += sign * A * S where S is a 16 x 16 block held in D layout: its register g IS the B operand of k-group g
+__device__ __forceinline__ double4_t blk_mma_a_reg(const double *a, double4_t s, double4_t acc, double sign, int lane) {
+    const int oa = (lane & 15) * TP + (lane >> 4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * a[oa + 4 * g], s[g], acc, 0, 0, 0);
+    return acc;
+}
+
 // Panel step at column k0: block 0 publishes inv(L11) into X; block b >= 1 overwrites the
 // tile A[k0 + 64 b ..][k0 ..] with L21 = A21 * inv(L11)^T.
 //
-// The 64 x 64 diagonal tile lives in REGISTERS: thread (i = t & 63, q = t >> 6) holds row i,
-// columns q, q+4, ..., q+60, so wave q is one residue class of columns and its lanes are the
-// rows.  Right-looking elimination, one barrier per column, a refined rsqrt instead of
-// sqrt + divide.  A taken branch costs ~45 cycles on this chip and this loop is a pure
-// latency chain, so both loops are FULLY UNROLLED and branch-free: column/step numbers are
-// compile-time constants (static register indices, statically known triangular extents),
-// every wave publishes its candidate for column j into its own LDS slot and readers index
-// the owner's slot, failures are folded into a flag that is stored once at the end.
-// The inverse is a forward substitution on all 64 right-hand sides with the same layout.
+// The chain of n pivots is the critical path of the whole factorisation, so the 64 x 64
+// diagonal tile is processed in four 16-column strips and everything that is not inherently
+// sequential runs on MFMA:
+//   strip kb  (ONE wave, no barrier, no LDS in the loop): lane i holds row 16 kb + i of the
+//             strip (all rows down to 63) in 16 registers.  Column j: pivot by v_readlane,
+//             refined rsqrt, scale (this IS the triangular solve for the rows below), then
+//             a[c] -= l_ij * l_cj with l_cj read-laned from lane c.  Fully unrolled, branch-free.
+//   update    T[rb, cb] -= L[rb, kb] L[cb, kb]^T for the blocks right of the strip: 4 MFMAs each,
+//             spread over the four waves; meanwhile one wave inverts the 16 x 16 diagonal block.
+//   inverse   off-diagonal blocks X[rb, cb] = -X[rb, rb] * sum_k L[rb, k] X[k, cb] level by level;
+//             the inner sum stays in registers: an accumulator tile is already the next B operand.
+// Two barriers per strip, three for the inverse.
 __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int ld, int k0,
                                                     double *__restrict__ X, int *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PanelSmem &sm = *reinterpret_cast<PanelSmem *>(smem_raw);
     const int t = threadIdx.x;
-    const int i = t & 63, q = t >> 6;
+    const int lane = t & 63, wave = t >> 6;
 
-    // ---- stage the tile coalesced, then pick this thread's row slice out of LDS
     for (int e = t; e < PANEL * PANEL; e += 256) {
         const int r = e >> 6, c = e & 63;
-        sm.d[r][c] = (c <= r) ? A[(size_t)(k0 + r) * ld + k0 + c] : 0.0;
+        sm.t[r][c] = (c <= r) ? A[(size_t)(k0 + r) * ld + k0 + c] : 0.0;
+        sm.x[r][c] = 0.0;
     }
     __syncthreads();
-    double a[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) a[m] = sm.d[i][q + 4 * m];
 
-    // ---- Cholesky of the tile
-    int first_bad = PANEL;
+    int first_bad = PANEL;  // meaningful in wave 0
 #pragma unroll
-    for (int j = 0; j < PANEL; ++j) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int jq = j & 3, jm = j >> 2, buf = j & 1;
-        sm.col[buf][q][i] = a[jm];  // only wave jq's slot holds column j
-        __syncthreads();
-        double piv = sm.col[buf][jq][j];
-        const double mine = sm.col[buf][jq][i];
-        double lc[16];
+    for (int kb = 0; kb < 4; ++kb) {
+        const int c0 = 16 * kb;
+        if (wave == 0) {
+            // ---- strip: rows c0 .. 63, columns c0 .. c0+15; lane i = row c0 + i
+            const int row = c0 + lane;
+            const bool live = row < PANEL;
+            double a[16];
 #pragma unroll
-        for (int m = jm; m < 16; ++m) lc[m] = sm.col[buf][jq][q + 4 * m];
-        const bool bad = !(piv > 0.0);  // also catches NaN
-        first_bad = (bad && first_bad == PANEL) ? j : first_bad;
-        piv = bad ? 1.0 : piv;
-        const double r = rsqrt_newton(piv);
-        const double lij = (i < j) ? 0.0 : mine * r;  // i == j: piv * r = sqrt(piv)
-        sm.rdiag[j] = r;                              // same value from every thread
-        // element jm: the owner stores L, waves to its right (column q + 4 jm > j) update
-        {
-            const double upd = __builtin_fma(-lij, lc[jm] * r, a[jm]);
-            a[jm] = (q == jq) ? lij : ((q > jq) ? upd : a[jm]);
+            for (int c = 0; c < 16; ++c) a[c] = live ? sm.t[live ? row : 0][c0 + c] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double piv = readlane_f64(a[j], j);
+                const bool bad = !(piv > 0.0);  // also catches NaN
+                first_bad = (bad && first_bad == PANEL) ? c0 + j : first_bad;
+                piv = bad ? 1.0 : piv;
+                const double r = rsqrt_newton(piv);
+                const double lj = a[j] * r;  // row j itself: piv * r = sqrt(piv)
+                a[j] = lj;
+                sm.rdiag[c0 + j] = r;  // uniform value, every lane stores it: no branch
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) a[c] = __builtin_fma(-lj, readlane_f64(lj, c), a[c]);
+            }
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) sm.t[row][c0 + c] = (c0 + c <= row) ? a[c] : 0.0;
+            }
         }
+        __syncthreads();
+        // ---- blocks right of the strip (rb >= cb > kb), round-robin over the waves
+        {
+            int q = 0;
 #pragma unroll
-        for (int m = jm + 1; m < 16; ++m) a[m] = __builtin_fma(-lij, lc[m] * r, a[m]);
+            for (int rb = kb + 1; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = kb + 1; cb <= rb; ++cb, ++q)
+                    if ((q & 3) == wave) {
+                        double *c = &sm.t[16 * rb][16 * cb];
+                        blk_store_d(c, lane, blk_mma_abt(&sm.t[16 * rb][c0], &sm.t[16 * cb][c0], blk_load_d(c, lane), -1.0, lane));
+                    }
+        }
+        // ---- inverse of the diagonal block: lane c < 16 owns column c of X[kb, kb]
+        if (wave == 3) {
+            const int c = lane & 15;
+            double xv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int u = 0; u < i; ++u) s = __builtin_fma(sm.t[c0 + i][c0 + u], xv[u], s);  // broadcast reads
+                xv[i] = ((c == i ? 1.0 : 0.0) - s) * sm.rdiag[c0 + i];                      // 0 above the diagonal
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sm.x[c0 + i][c0 + c] = xv[i];
+            }
+        }
+        __syncthreads();
     }
     if (first_bad != PANEL && blockIdx.x == 0 && t == 0 && info[0] == 0) info[0] = k0 + first_bad + 1;
-    // ---- L11 to LDS (lower part) for the substitution
-#pragma unroll
-    for (int m = 0; m < 16; ++m) sm.d[i][q + 4 * m] = (q + 4 * m <= i) ? a[m] : 0.0;
-    __syncthreads();
 
-    // ---- X11 = inv(L11): x[m] accumulates sum_t L[i][t] X[t][c] for c = q + 4m.
-    //      Step tt touches only columns c <= tt, i.e. m <= tt >> 2 (m == tt >> 2 iff q <= tt & 3).
-    double x[16];
+    // ---- off-diagonal blocks of X = inv(L11), by distance d from the diagonal
 #pragma unroll
-    for (int m = 0; m < 16; ++m) x[m] = 0.0;
+    for (int d = 1; d < 4; ++d) {
 #pragma unroll
-    for (int tt = 0; tt < PANEL; ++tt) {
-        const int tq = tt & 3, tm = tt >> 2, buf = tt & 1;
-        const double rd = sm.rdiag[tt];
-        const bool fin = i == tt;  // one lane per wave finalises its entries of row tt
+        for (int rb = d; rb < 4; ++rb) {
+            if (((rb - d) & 3) == wave) {
+                const int cb = rb - d;
+                double4_t s = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int m = 0; m <= tm; ++m) {
-            const double unit = (m == tm) ? ((q == tq) ? 1.0 : 0.0) : 0.0;
-            const double xv = (unit - x[m]) * rd;
-            const bool live = (m < tm) || (q <= tq);
-            x[m] = (fin && live) ? xv : x[m];
-            sm.row[buf][fin ? q * 16 + m : PANEL + i] = xv;  // other lanes write to a dump slot: no branch
+                for (int k = cb; k < rb; ++k) s = blk_mma_ab(&sm.t[16 * rb][16 * k], &sm.x[16 * k][16 * cb], s, lane);
+                const double4_t z = {0.0, 0.0, 0.0, 0.0};
+                blk_store_d(&sm.x[16 * rb][16 * cb], lane, blk_mma_a_reg(&sm.x[16 * rb][16 * rb], s, z, -1.0, lane));
+            }
         }
         __syncthreads();
-        const double l = (i > tt) ? sm.d[i][tt] : 0.0;
-#pragma unroll
-        for (int m = 0; m <= tm; ++m) {
-            const double xr = sm.row[buf][q * 16 + m];
-            const bool live = (m < tm) || (q <= tq);
-            x[m] = live ? __builtin_fma(l, xr, x[m]) : x[m];  // l == 0 for rows already final
-        }
     }
-#pragma unroll
-    for (int m = 0; m < 16; ++m) sm.x[i][q + 4 * m] = x[m];  // exactly zero above the diagonal
-    __syncthreads();
 
     if (blockIdx.x == 0) {
         for (int e = t; e < PANEL * PANEL; e += 256) {
             const int r = e >> 6, c = e & 63;
-            X[(size_t)(k0 + r) * ld + k0 + c] = sm.x[r][c];
+            X[(size_t)(k0 + r) * ld + k0 + c] = sm.x[r][c];  // exactly zero above the diagonal
         }
         return;
     }
@@ -149,8 +197,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
     const int r0 = k0 + PANEL * blockIdx.x;
     Acc64 acc;
     acc.zero();
-    const double *arow = A + (size_t)r0 * ld + k0;
-    const double *pa = arow + (size_t)(t >> 2) * ld + (t & 3) * 8;
+    const double *pa = A + (size_t)(r0 + (t >> 2)) * ld + k0 + (t & 3) * 8;
     tile64_mac<false>(
         acc, sm.mm, 0, PANEL, [&](int kb, double(&v)[8]) { load8d<true>(pa + kb, v); },
         [&](int kb, double(&v)[8]) {  // B[k][c] = X11[c][k], straight from LDS

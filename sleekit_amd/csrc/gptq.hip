@@ -75,13 +75,6 @@ struct WindowSmem {
     double u[ULEAF][ULEAF + 1];
 };
 
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-    const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 // codebook.py:56-65 with the divide replaced by Markstein's sequence: with y = RN(1/step),
 //   q0 = RN(t0 y);  r = t0 - step q0 (exact in one fma);  t = RN(q0 + r y) == RN(t0 / step)
 // for every t0 whose quotient neither overflows nor underflows (rint of an underflowing
@@ -153,7 +146,7 @@ __device__ __forceinline__ bool leaf_registers(WindowSmem &sm, int row, int lane
 template <bool IN_LDS>
 __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, float *__restrict__ Eg,
                                                      const double *__restrict__ U, int R, int n, int w0, int w1,
-                                                     Grid g, float inv_step, int fast_ok, OpTable tab) {
+                                                     Grid g, float inv_step, int fast_ok, int dbg, OpTable tab) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     WindowSmem &sm = *reinterpret_cast<WindowSmem *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -195,6 +188,8 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
 
     for (int oi = 0; oi < tab.count; ++oi) {
         const Op op = tab.op[oi];
+        if ((dbg & 1) && op.kind == OP_LEAF) continue;
+        if ((dbg & 2) && op.kind != OP_LEAF) continue;
         if (op.kind == OP_LEAF) {
             const int a = op.a, b = op.b, w = b - a;
             const bool staged = IN_LDS && w <= ULEAF;
@@ -403,6 +398,7 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
     memcpy(&step_bits, &g.step, 4);
     const int fast_ok = (step_bits & 0x7FFFFFu) != 0x7FFFFFu && g.step > 9.0e-13f && g.step < 1.0e12f &&
                         getenv("SLK_NO_FAST_LEAF") == nullptr;
+    const int dbg = getenv("SLK_WIN_DBG") ? atoi(getenv("SLK_WIN_DBG")) : 0;
     static bool attr_set = false;
     if (!attr_set) {
         SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gptq_window<true>),
@@ -438,11 +434,11 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
                 if (in_lds)
                     SLK_RUN("gptq_window", fl * R, wbytes, s,
                             k_gptq_window<true><<<row_tiles, 512, sizeof(WindowSmem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g,
-                                                                                        inv_step, fast_ok, tab));
+                                                                                        inv_step, fast_ok, dbg, tab));
                 else
                     SLK_RUN("gptq_window_wide", fl * R, wbytes, s,
                             k_gptq_window<false><<<row_tiles, 512, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, g, inv_step, fast_ok,
-                                                                           tab));
+                                                                           dbg, tab));
             }
         } else {
             const double K = st.b - st.a, N = st.c - st.b;

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void k_permute_out(const float *__restrict__ Q
 struct WindowSmem {
     float q[RB][WPITCH];
     float e[RB][WPITCH];
-    double u[ULEAF][ULEAF + 1];
+    double u[ULEAF][ULEAF + 1];  // leaf block of U, STRICTLY upper part (zero on/below the diagonal and beyond the width)
+    double ud[ULEAF];            // its diagonal (1 beyond the width)
+    double urd[ULEAF];           // 1 / diagonal, by true division
 };
 
 // codebook.py:56-65 with the divide replaced by Markstein's sequence: with y = RN(1/step),
@@ -91,53 +93,61 @@ __device__ __forceinline__ float grid_value_fast(float x, const Grid g, float in
     return t * g.step + g.zero;
 }
 
-// LEAF, register path (width <= 32, window in LDS).  A wave owns two rows, 32 lanes per row;
-// lane c keeps column a + c of its row in a register together with U[a + i][a + c], i < 32.
-// Step i: the value of column i is read-laned to every lane of its half-wave, all of them
-// compute q_i and err_i redundantly (no second broadcast), then update their own column:
-//     x_c <- float32(float64(x_c) - err_i * U[i][c])                      (obq.py:114-118)
-// err_i = float64(x_i - q_i) / U[i][i] uses the same exact-division sequence in float64 with
-// the reciprocals taken once per leaf by true division.
-__device__ __forceinline__ bool leaf_registers(WindowSmem &sm, int row, int lane, int a_rel, int w, const Grid g,
+// LEAF, register path (width <= 32, window in LDS), run by waves 0-3 of the workgroup: a wave
+// owns FOUR rows, 16 lanes per row; lane c keeps columns a + c and a + 16 + c of its row in two
+// registers.  Step i: column i's value is read-laned out of the four rows and selected per
+// row group, every lane recomputes q_i and err_i for its own row (no second broadcast), then
+// updates its two columns:  x_c <- float32(float64(x_c) - err_i * U[i][c])   (obq.py:114-118)
+// err_i = float64(x_i - q_i) / U[i][i] uses the exact-division fma sequence with reciprocals
+// taken once per leaf by a true division.  The loop is issue-bound (~35 instructions a step),
+// which is why four rows share a wave and the other four waves of the workgroup stay parked
+// at the barrier: two waves per SIMD would just take turns (measured 430 -> ~230 cycles/step).
+__device__ __forceinline__ void leaf_registers(WindowSmem &sm, int wave, int lane, int a_rel, int w, const Grid g,
                                                float inv_step) {
-    const int l32 = lane & 31;
-    const bool mine = l32 < w;
-    const double uc = mine ? sm.u[l32][l32] : 1.0;
-    // Markstein's exception: a divisor whose significand is all ones
-    const bool odd = (__double_as_longlong(uc) & 0xFFFFFFFFFFFFFLL) == 0xFFFFFFFFFFFFFLL;
-    if (__any(odd)) return false;
-    const double rc = 1.0 / uc;
-    float x = mine ? sm.q[row][a_rel + l32] : 0.0f;
-    double u[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) u[i] = (i < w && mine && l32 > i) ? sm.u[i][l32] : 0.0;
-    float qfin = 0.0f, efin = 0.0f;
+    const int c16 = lane & 15, rg = lane >> 4;
+    const int row = 4 * wave + rg;
+    const bool m0 = c16 < w, m1 = c16 + 16 < w;
+    float x0 = m0 ? sm.q[row][a_rel + c16] : 0.0f, x1 = m1 ? sm.q[row][a_rel + 16 + c16] : 0.0f;
+    float q0 = 0.0f, q1 = 0.0f, e0 = 0.0f, e1 = 0.0f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         if (i < w) {  // uniform
-            const int xb = __float_as_int(x);
-            const float xa = __int_as_float(__builtin_amdgcn_readlane(xb, i));
-            const float xbv = __int_as_float(__builtin_amdgcn_readlane(xb, 32 + i));
-            const float xi = lane < 32 ? xa : xbv;
-            const double uii = readlane_f64(uc, i), rii = readlane_f64(rc, i);
+            const int src = i & 15;
+            const int xb = __float_as_int(i < 16 ? x0 : x1);
+            const float s0 = __int_as_float(__builtin_amdgcn_readlane(xb, src));
+            const float s1 = __int_as_float(__builtin_amdgcn_readlane(xb, 16 + src));
+            const float s2 = __int_as_float(__builtin_amdgcn_readlane(xb, 32 + src));
+            const float s3 = __int_as_float(__builtin_amdgcn_readlane(xb, 48 + src));
+            const float xi = (rg & 2) ? ((rg & 1) ? s3 : s2) : ((rg & 1) ? s1 : s0);
+            // diagonal and its reciprocal: LDS broadcast reads, off the dependency chain
+            const double uii = sm.ud[i], rii = sm.urd[i];
             const float q = grid_value_fast(xi, g, inv_step);
             const double d = (double)(xi - q);
-            const double q0 = d * rii;
-            const double rem = __builtin_fma(-uii, q0, d);
-            const double err = __builtin_fma(rem, rii, q0);
-            if (l32 == i) {
-                qfin = q;
-                efin = (float)err;
+            const double qq = d * rii;
+            const double rem = __builtin_fma(-uii, qq, d);
+            const double err = __builtin_fma(rem, rii, qq);
+            const float ef = (float)err;
+            const bool here = c16 == src;
+            if (i < 16) {
+                q0 = here ? q : q0;
+                e0 = here ? ef : e0;
+            } else {
+                q1 = here ? q : q1;
+                e1 = here ? ef : e1;
             }
-            const double p = err * u[i];
-            x = (float)((double)x - p);
+            // the staged block is zero on and below the diagonal: only later columns move
+            if (i < 15) x0 = (float)((double)x0 - err * sm.u[i][c16]);
+            x1 = (float)((double)x1 - err * sm.u[i][c16 + 16]);
         }
     }
-    if (mine) {
-        sm.q[row][a_rel + l32] = qfin;
-        sm.e[row][a_rel + l32] = efin;
+    if (m0) {
+        sm.q[row][a_rel + c16] = q0;
+        sm.e[row][a_rel + c16] = e0;
     }
-    return true;
+    if (m1) {
+        sm.q[row][a_rel + 16 + c16] = q1;
+        sm.e[row][a_rel + 16 + c16] = e1;
+    }
 }
 
 // One workgroup = 512 threads = 8 waves = RB rows.  In a LEAF each wave owns two rows,
@@ -153,12 +163,15 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
     const int r0 = blockIdx.x * RB;
     const int width = w1 - w0;
 
-    // tile accessors: LDS copy of the window, or the global arrays themselves (very wide leaves)
-    auto qref = [&](int r, int c) -> volatile float & {
-        return IN_LDS ? *(volatile float *)&sm.q[r][c - w0] : *(volatile float *)&Qp[(size_t)(r0 + r) * n + c];
+    // tile accessors: LDS copy of the window, or the global arrays themselves (very wide leaves).
+    // Plain accesses: every producer/consumer pair below is separated by a __syncthreads().
+    auto qld = [&](int r, int c) -> float { return IN_LDS ? sm.q[r][c - w0] : Qp[(size_t)(r0 + r) * n + c]; };
+    auto eld = [&](int r, int c) -> float { return IN_LDS ? sm.e[r][c - w0] : Eg[(size_t)(r0 + r) * n + c]; };
+    auto qst = [&](int r, int c, float v) {
+        if (IN_LDS) sm.q[r][c - w0] = v; else Qp[(size_t)(r0 + r) * n + c] = v;
     };
-    auto eref = [&](int r, int c) -> volatile float & {
-        return IN_LDS ? *(volatile float *)&sm.e[r][c - w0] : *(volatile float *)&Eg[(size_t)(r0 + r) * n + c];
+    auto est = [&](int r, int c, float v) {
+        if (IN_LDS) sm.e[r][c - w0] = v; else Eg[(size_t)(r0 + r) * n + c] = v;
     };
     // Register prefetch of the next staged leaf's U block (<= 32 x 32 doubles over 512 threads).
     double pu[2] = {0.0, 0.0};
@@ -170,8 +183,8 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
             if (w > ULEAF) return;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int e = t + 512 * h;
-                if (e < w * w) pu[h] = U[(size_t)(nx.a + e / w) * n + nx.a + e % w];
+                const int e = t + 512 * h, i = e >> 5, j = e & 31;
+                if (i < w && j < w && j >= i) pu[h] = U[(size_t)(nx.a + i) * n + nx.a + j];
             }
             return;
         }
@@ -186,6 +199,59 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
     }
     __syncthreads();
 
+    // ---- UPDATE machinery: Q[:, b:c] -= E[:, a:b] @ U[a:b, b:c] on the 16 rows of this tile.
+    // The target columns are cut in 16-wide MFMA blocks; wave v takes blocks v, v + 8, ...  A
+    // ROUND is (block, 64-deep K chunk).  Operands of U come straight from global memory (every
+    // workgroup streams the same panel out of L2), so the loads of round r+1 are issued before
+    // the MFMAs of round r, and round 0 of an update is issued BEFORE the leaf that precedes it.
+    const int lr = lane & 15, lk = lane >> 4;
+    const bool row_ok = IN_LDS || r0 + lr < R;
+    double cur[16];
+    bool have_round0 = false;
+    auto load_round = [&](const Op &u, int q, int kc, double(&bv)[16]) {
+        const int nblk = (u.c - u.b + 15) / 16;
+        const int blk = wave + 8 * q;
+        const int col = u.b + blk * 16 + lr;
+        const bool ok = blk < nblk && col < u.c;
+        const int cc = min(col, u.c - 1);
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const int k = u.a + 64 * kc + 4 * s4 + lk;
+            // clamp + multiply-mask: never a branch around a load
+            bv[s4] = U[(size_t)min(k, u.b - 1) * n + cc] * ((k < u.b && ok) ? 1.0 : 0.0);
+        }
+    };
+    // generic leaf (any width, true divides): the whole workgroup in lockstep, 32 lanes per row,
+    // one barrier per column.  Rare (width > 32, or a diagonal hitting the exact-division
+    // exception), so simplicity wins.
+    auto generic_leaf = [&](int a, int b, bool staged) {
+        const int myrow = 2 * wave + (lane >> 5), l = lane & 31;
+        const bool live = IN_LDS || (r0 + myrow < R);
+        for (int i = a; i < b; ++i) {
+            float x = 0.0f, q = 0.0f;
+            double err = 0.0;
+            if (live) {
+                x = qld(myrow, i);
+                q = grid_value(x, g);
+                const double uii = staged ? sm.ud[i - a] : U[(size_t)i * n + i];
+                err = (double)(x - q) / uii;
+            }
+            __syncthreads();  // everyone has read column i before lane 0 overwrites it
+            if (live) {
+                for (int j = i + 1 + l; j < b; j += 32) {
+                    const double uij = staged ? sm.u[i - a][j - a] : U[(size_t)i * n + j];
+                    const double p = err * uij;
+                    qst(myrow, j, (float)((double)qld(myrow, j) - p));
+                }
+                if (l == 0) {
+                    est(myrow, i, (float)err);
+                    qst(myrow, i, q);
+                }
+            }
+            __syncthreads();
+        }
+    };
+
     for (int oi = 0; oi < tab.count; ++oi) {
         const Op op = tab.op[oi];
         if ((dbg & 1) && op.kind == OP_LEAF) continue;
@@ -196,77 +262,70 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
             if (staged) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int e = t + 512 * h;
-                    if (e < w * w) sm.u[e / w][e % w] = pu[h];
+                    const int e = t + 512 * h, i = e >> 5, j = e & 31;  // all 32 x 32 slots
+                    const bool in = i < w && j < w;
+                    sm.u[i][j] = (in && j > i) ? pu[h] : 0.0;
+                    if (i == j) {
+                        const double dg = in ? pu[h] : 1.0;
+                        sm.ud[i] = dg;
+                        sm.urd[i] = 1.0 / dg;
+                    }
                 }
             }
             __syncthreads();
             if (IN_LDS) prefetch_leaf(oi + 1);  // flies during this leaf and the update behind it
-            const int row = 2 * wave + (lane >> 5), l32 = lane & 31;
-            bool done = false;
-            if (staged && fast_ok) done = leaf_registers(sm, row, lane, a - w0, w, g, inv_step);
-            const bool live = IN_LDS || (r0 + row < R);
-            if (!done && live) {
-                for (int i = a; i < b; ++i) {
-                    const float x = qref(row, i);
-                    const float q = grid_value(x, g);
-                    const float d = x - q;
-                    const double uii = staged ? sm.u[i - a][i - a] : U[(size_t)i * n + i];
-                    const double err = (double)d / uii;
-                    for (int j = i + 1 + l32; j < b; j += 32) {
-                        const double uij = staged ? sm.u[i - a][j - a] : U[(size_t)i * n + j];
-                        const double p = err * uij;
-                        const double v = (double)qref(row, j);
-                        qref(row, j) = (float)(v - p);
-                    }
-                    if (l32 == 0) {
-                        eref(row, i) = (float)err;
-                        qref(row, i) = q;
-                    }
-                }
+            if (IN_LDS && oi + 1 < tab.count && tab.op[oi + 1].kind == OP_UPDATE && !(dbg & 2)) {
+                load_round(tab.op[oi + 1], 0, 0, cur);
+                have_round0 = true;
+            }
+            bool use_fast = staged && fast_ok;
+            if (use_fast) {
+                // exact-division exception: a diagonal entry whose significand is all ones
+                const int c = lane & 31;
+                const bool odd = c < w && (__double_as_longlong(sm.ud[c]) & 0xFFFFFFFFFFFFFLL) == 0xFFFFFFFFFFFFFLL;
+                use_fast = !__syncthreads_or(odd);
+            }
+            if (use_fast) {
+                // waves 0-3 take four rows each; waves 4-7 go straight to the barrier
+                if (wave < 4) leaf_registers(sm, wave, lane, a - w0, w, g, inv_step);
+            } else {
+                generic_leaf(a, b, staged);
             }
             __syncthreads();
         } else {
-            // Q[:, b:c] -= E[:, a:b] @ U[a:b, b:c] on the 16 rows of this tile
             const int a = op.a, b = op.b, c = op.c;
             const int nblk = (c - b + 15) / 16;
-            const int lr = lane & 15, lk = lane >> 4;
-            const bool row_ok = IN_LDS || r0 + lr < R;
-            for (int blk0 = wave; blk0 < nblk; blk0 += 16) {
-                const int blk1 = blk0 + 8;
-                const int col0 = b + blk0 * 16 + lr, col1 = b + blk1 * 16 + lr;
-                const bool ok0 = col0 < c, ok1 = blk1 < nblk && col1 < c;
-                double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                for (int k0 = a; k0 < b; k0 += 64) {
-                    double av[16], b0[16], b1[16];
+            const int nq = (nblk + 7) / 8, nchunk = (b - a + 63) / 64;
+            if (!have_round0) load_round(op, 0, 0, cur);
+            have_round0 = false;
+            for (int q = 0; q < nq; ++q) {
+                const int blk = wave + 8 * q;
+                const int col = b + blk * 16 + lr;
+                const bool ok = blk < nblk && col < c;
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                for (int kc = 0; kc < nchunk; ++kc) {
+                    double nxt[16];
+                    const bool last = (kc + 1 == nchunk) && (q + 1 == nq);
+                    if (!last) load_round(op, (kc + 1 == nchunk) ? q + 1 : q, (kc + 1 == nchunk) ? 0 : kc + 1, nxt);
+                    if (blk < nblk) {
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) {
-                        const int k = k0 + 4 * s + lk;
-                        const bool k_ok = k < b;
-                        b0[s] = (k_ok && ok0) ? U[(size_t)k * n + col0] : 0.0;
-                        b1[s] = (k_ok && ok1) ? U[(size_t)k * n + col1] : 0.0;
-                        av[s] = (k_ok && row_ok) ? (double)eref(lr, k) : 0.0;
+                        for (int s4 = 0; s4 < 16; ++s4) {
+                            const int k = a + 64 * kc + 4 * s4 + lk;
+                            const double av = (k < b && row_ok) ? (double)eld(lr, min(k, b - 1)) : 0.0;
+                            if (a + 64 * kc + 4 * s4 < b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, cur[s4], acc, 0, 0, 0);
+                        }
                     }
+                    if (!last) {
 #pragma unroll
-                    for (int s = 0; s < 16; ++s)
-                        if (k0 + 4 * s < b) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], b0[s], acc0, 0, 0, 0);
-                    if (blk1 < nblk) {
-#pragma unroll
-                        for (int s = 0; s < 16; ++s)
-                            if (k0 + 4 * s < b) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], b1[s], acc1, 0, 0, 0);
+                        for (int s4 = 0; s4 < 16; ++s4) cur[s4] = nxt[s4];
                     }
                 }
+                if (ok) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = lk + 4 * r;
-                    if (IN_LDS || r0 + row < R) {
-                        if (ok0) {
-                            const double v = (double)qref(row, col0);
-                            qref(row, col0) = (float)(v - acc0[r]);
-                        }
-                        if (ok1) {
-                            const double v = (double)qref(row, col1);
-                            qref(row, col1) = (float)(v - acc1[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = lk + 4 * r;
+                        if (IN_LDS || r0 + row < R) {
+                            qst(row, col, (float)((double)qld(row, col) - acc[r]));
                         }
                     }
                 }

@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic layers cycled through the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--streams", type=str, default="3,2", help="factor,loop stream counts")
+    ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts (default 3,2; 3,min(8,2N) on N>1 ranks)")
     ap.add_argument("--stages", action="store_true", help="also print per-kernel timing table to stderr")
     return ap.parse_args()
 
@@ -69,11 +69,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # (a rehearsal may put several ranks on one GPU)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend_name = os.environ.get("SLK_DIST_BACKEND", "nccl")  # "gloo" only to rehearse on a 1-GPU box
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend_name)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from sleekit_amd import _device as dev
@@ -96,8 +101,9 @@ def main():
         host_layer0 = {k: base[0][k].cpu().numpy() for k in ("W", "H", "scale")}
     t_setup = time.time() - t_setup
 
-    backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True,
-                               overlap=tuple(int(x) for x in args.streams.split(",")))
+    # row shards shrink with N while the leaf chains do not: more loops in flight on more ranks
+    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else (3, 2 if world == 1 else min(8, 2 * world))
+    backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=streams)
 
     def step():
         shards = sdist.quantize_stream(layers, backend)
@@ -128,19 +134,25 @@ def main():
     # layer error of the last step (sanity: finite, GPTQ-sized) -- bookkeeping, not timed
     err0 = float(sdist.layer_error(shards[0]["row_err"], R).item())
 
-    # ---- per-kernel timing of one more step with HIP events around every launch
+    # ---- roofline of the dominant kernel: the SAME K steps once more (same streams, same overlap)
+    #      with a pair of HIP events around every launch, recorded on the launch's own stream
     roofline, table = None, []
     if not args.no_profile:
         fence()
         _lib.lib.slk_profile_reset()
         _lib.lib.slk_profile_enable(1)
-        # one stream for this pass: kernels of different layers must not share the chip while timed
-        sdist.quantize_stream(layers, sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=False))
-        torch.cuda.synchronize()
+        t0p = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        t_prof = time.perf_counter() - t0p
         _lib.lib.slk_profile_enable(0)
         table = _lib.profile_report()
         _lib.lib.slk_profile_reset()
-        fence()
+        traffic_db = {}
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic_db = json.load(open(tpath)).get("bytes_per_launch", {})
         if table:
             top = max(table, key=lambda k: k["total_ms"])
             secs = top["total_ms"] * 1e-3
@@ -149,18 +161,29 @@ def main():
             t_bytes = top["bytes"] / PEAK["hbm"][0]
             if kind and t_flops >= t_bytes:
                 achieved, peak, unit, bound = top["flops"] / secs / 1e12, PEAK[kind][0] / 1e12, "TFLOP/s", "mfma"
+                per_launch = top["flops"] / top["launches"]
             else:
                 achieved, peak, unit, bound = top["bytes"] / secs / 1e9, PEAK["hbm"][0] / 1e9, "GB/s", "hbm"
+                per_launch = top["bytes"] / top["launches"]
             roofline = {
                 "kernel": top["kernel"], "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                "frac": round(achieved / peak, 4), "traffic": None,
-                "launches_per_step": top["launches"], "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
-                "share_of_step": round(top["total_ms"] / sum(k["total_ms"] for k in table), 3),
-                "peak_kind": kind or "hbm",
+                "frac": round(achieved / peak, 4), "traffic": traffic_db.get(top["kernel"]),
+                "launches": top["launches"], "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
+                "algorithmic_per_launch": per_launch, "peak_kind": kind or "hbm",
+                "share_of_kernel_time": round(top["total_ms"] / sum(k["total_ms"] for k in table), 3),
+                "steps_with_events_ms": round(1e3 * t_prof / args.steps, 3),
             }
         if args.stages and rank == 0:
-            tot = sum(k["total_ms"] for k in table)
-            for k in sorted(table, key=lambda k: -k["total_ms"]):
+            # clean per-kernel table: one more pass on ONE stream (no kernel shares the chip)
+            _lib.lib.slk_profile_enable(1)
+            sdist.quantize_stream(layers, sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=False))
+            torch.cuda.synchronize()
+            _lib.lib.slk_profile_enable(0)
+            seq = _lib.profile_report()
+            _lib.lib.slk_profile_reset()
+            tot = sum(k["total_ms"] for k in seq)
+            print(f"  single-stream pass: {tot:.3f} ms of kernels for {L} layers", file=sys.stderr)
+            for k in sorted(seq, key=lambda k: -k["total_ms"]):
                 print(
                     f"  {k['kernel']:<20s} {k['launches']:5d} launches {k['total_ms']:9.3f} ms {100 * k['total_ms'] / tot:5.1f}%"
                     f"  {k['flops'] / max(k['total_ms'], 1e-9) / 1e9:9.2f} TFLOP/s {k['bytes'] / max(k['total_ms'], 1e-9) / 1e6:9.1f} GB/s",
@@ -197,6 +220,7 @@ def main():
                             f"act_order=diag, damp=0.01, local-search moves={args.moves}, layer error included",
                 "layers_per_step": L, "rows": R, "cols": n, "row_sharding": f"{world} ranks x {R // world} rows",
                 "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(t_setup, 1),
+                "streams": {"factor": streams[0], "loop": streams[1]},
             },
             "roofline": roofline, "cpu_baseline": cpu, "layer_error": err0,
         }

@@ -1,0 +1,89 @@
+"""The row-shard stream with the REAL HIP backend, two ranks sharing the one GPU (gloo transport).
+
+RCCL refuses two ranks on one device, so the collective here is gloo on device tensors; the
+scheduling, streams, events and kernels are exactly what bench.py runs under RCCL.  Each rank's
+shard must equal the corresponding rows of the single-process result bit for bit.
+"""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, size, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        from sleekit_amd import codebook, synth
+        from sleekit_amd import dist as sdist
+
+        layers = _layers(torch.device("cuda", 0))
+        be = sdist.HipBackend(codebook.UniformCodebook(8, -1, 1), "diag", 0.01, 0, with_error=True)
+        shards = sdist.quantize_stream(layers, be)
+        torch.cuda.synchronize()
+        errs = [float(sdist.layer_error(s["row_err"], layers[i]["W"].shape[0])) for i, s in enumerate(shards)]
+        q.put((rank, [(s["rows"], s["idx"].cpu().numpy(), s["Q"].cpu().numpy(), int(s["info"].item())) for s in shards], errs))
+    finally:
+        dist.destroy_process_group()
+
+
+def _layers(device):
+    from sleekit_amd import synth
+
+    out = []
+    for i, (R, n) in enumerate([(96, 172), (130, 256), (64, 96), (256, 768), (50, 64)]):
+        L = synth.make_layer(R, n, 3000 + i)
+        out.append({k: torch.from_numpy(L[k]).to(device) for k in ("W", "H", "scale")})
+    return out
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_one_gpu_match_single_process():
+    import torch.multiprocessing as mp
+
+    from sleekit_amd import codebook
+    from sleekit_amd import dist as sdist
+
+    dev = torch.device("cuda", 0)
+    layers = _layers(dev)
+    cb = codebook.UniformCodebook(8, -1, 1)
+    single = sdist.quantize_stream(layers, sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True))
+    plain = sdist.quantize_stream(layers, sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True, overlap=False))
+    torch.cuda.synchronize()
+    for a, b in zip(single, plain):  # stream overlap changes nothing
+        assert torch.equal(a["idx"], b["idx"]) and torch.equal(a["Q"], b["Q"]) and torch.equal(a["row_err"], b["row_err"])
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for l, layer in enumerate(layers):
+        R = layer["W"].shape[0]
+        (lo0, hi0), idx0, q0, info0 = got[0][1][l]
+        (lo1, hi1), idx1, q1, info1 = got[1][1][l]
+        assert (lo0, hi1) == (0, R) and hi0 == lo1 and info0 == 0 and info1 == 0
+        assert np.array_equal(np.concatenate([idx0, idx1]), single[l]["idx"].cpu().numpy())
+        assert np.array_equal(np.concatenate([q0, q1]), single[l]["Q"].cpu().numpy())
+        want = float(single[l]["row_err"].double().sum() / R)
+        assert abs(got[0][2][l] - want) <= 1e-6 * abs(want)

@@ -139,6 +139,29 @@ int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int
                      double hi, int moves, uint8_t *idx, void *workspace, size_t ws_bytes,
                      slk_stream_t stream);
 
+/* Scale selection: the callers' pre-step -------------------------- */
+/* compute_non_saturating_scaling (sleekit/scaling.py:44-55): scale[r] = max(max_r / hi_code,
+ * min_r / lo_code, 1e-16) with the codebook's extreme values lo_code < 0 < hi_code.          */
+int slk_scale_minmax(const float *W, int R, int n, double lo_code, double hi_code, float *scale,
+                     slk_stream_t stream);
+/* compute_norm_scaling (sleekit/scaling.py:35-41): sqrt(max(mean(row^2), 1e-16)), float32,
+ * row sums in NumPy's pairwise order.                                                        */
+int slk_scale_norm(const float *W, int R, int n, float *scale, slk_stream_t stream);
+/* compute_min_mse_scaling with H = None (hdiag NULL) or a diagonal Hessian (sleekit/scaling.py:
+ * 84-134): for each factor f (float32, in order) quantize the row round-to-nearest with scale
+ * f * base[r], take the error sum_j [hdiag_j] E_j^2 in NumPy's summation order, keep the first
+ * minimum; out[r] = base[r] * best factor.                                                   */
+int slk_scale_search(const float *W, const float *base, const float *factors, int n_factors,
+                     const float *hdiag, int R, int n, int levels, double lo, double hi, float *out,
+                     slk_stream_t stream);
+/* Book-keeping of the searches whose row errors come from slk_row_errors (full Hessian, OBQ-aware;
+ * sleekit/scaling.py:131-133, 187-189): init != 0 resets best_err / best_f to +inf; err != NULL
+ * applies `better = err < best_err`.                                                          */
+int slk_search_step(const float *err, float factor, int R, float *best_err, float *best_f, int init,
+                    slk_stream_t stream);
+/* out[r] = a[r] * b[r]  (b != NULL)  or  a[r] * c. */
+int slk_scale_times(const float *a, const float *b, float c, int R, float *out, slk_stream_t stream);
+
 /* Diagnostics used by tests ------------------------------------------------ */
 /* NumPy-ordered float32 mean of diag(H) -> out[0]. */
 int slk_diag_mean(const float *H, int n, float *out, void *workspace, size_t ws_bytes,

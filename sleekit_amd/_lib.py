@@ -48,6 +48,11 @@ PROTOTYPES = {
     ),
     "slk_row_errors": (c_int, [P, P, P, c_int, c_int, P, P, P, c_size_t, P]),
     "slk_local_search": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_double, c_int, P, P, c_size_t, P]),
+    "slk_scale_minmax": (c_int, [P, c_int, c_int, c_double, c_double, P, P]),
+    "slk_scale_norm": (c_int, [P, c_int, c_int, P, P]),
+    "slk_scale_search": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_double, c_double, P, P]),
+    "slk_search_step": (c_int, [P, c_float, c_int, P, P, c_int, P]),
+    "slk_scale_times": (c_int, [P, P, c_float, c_int, P, P]),
     "slk_diag_mean": (c_int, [P, c_int, P, P, c_size_t, P]),
     "slk_probe_mfma_f64": (c_int, [P, c_int, c_int, P]),
     "slk_probe_mfma_f32": (c_int, [P, c_int, c_int, P]),

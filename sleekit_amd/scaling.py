@@ -1,16 +1,20 @@
-"""Drop-in for `sleekit.scaling`: per-row scaling around the quantization loop.
+"""Drop-in for `sleekit.scaling`: per-row scaling around the quantization loop, on the GPU.
 
-`apply_scaling*` and `quantize_with_scaling` (sleekit/scaling.py:11-33, 58-81) wrap the hot
-path and run on the GPU.  The scale *searches* (`compute_min_mse_scaling`,
-`compute_obq_scaling`, `compute_scaling` and the two closed-form scales; scaling.py:35-55,
-84-238) are the callers' pre-step, listed as "next" in SURVEY.md section 8(f): the names
-exist and raise until their kernels land.
+Same names, arguments and defaults as the reference module (sleekit/scaling.py).  The device
+path scales axis 0 of a 2-D weight matrix -- the only layout the callers use (`Sleekit.quantize`
+flattens conv weights first, statistics.py:166).
+
+Known deviations, all confined to the scale SEARCH helpers (the quantization path itself is
+bit-exact): Hessians are taken in float32 (the reference's `hessianN` / float64-diagonal variants
+promote to float64), and `compute_obq_scaling` evaluates errors in the original column order
+instead of the permuted one (same sums, different float32 summation order).
 """
 
 import numpy as np  # noqa: F401  (star-importers of the reference rely on `np` leaking from here)
 import torch
 
 from . import _device as dev
+from . import _lib
 from . import engine
 from .obq import _quantize_opt_block, compute_hessian_chol, compute_hessian_order, quantize_opt  # noqa: F401
 
@@ -20,6 +24,11 @@ def _check_axis0(data, scale, axis):
     if axis != 0 or data.ndim != 2:
         raise NotImplementedError("the device path scales axis 0 of a 2-D weight matrix (what the hot path uses)")
     assert data.shape[0] == scale.shape[0]
+
+
+def _rows_only(data, axis):
+    if axis != 0 or data.ndim != 2:
+        raise NotImplementedError("the device path scales axis 0 of a 2-D weight matrix (what the hot path uses)")
 
 
 def apply_scaling(data, scale, axis=0):
@@ -39,6 +48,33 @@ def apply_scaling_in_place(data, scale, axis=0):
         data[...] = dev.like_input(out, data)
 
 
+def compute_norm_scaling(data, axis=0):
+    """Scale that brings the mean square of every row to 1 (sleekit/scaling.py:35-41)."""
+    _rows_only(data, axis)
+    W = dev.to_device(data)
+    out = torch.empty(W.shape[0], dtype=torch.float32, device=W.device)
+    _lib.check(_lib.lib.slk_scale_norm(dev.ptr(W), W.shape[0], W.shape[1], dev.ptr(out), dev.stream_handle()))
+    return dev.like_input(out, data)
+
+
+def _no_clip_scale(W, codebook):
+    if codebook.min() >= 0 or codebook.max() <= 0:
+        raise RuntimeError("Codebook should have both negative and positive values.")
+    out = torch.empty(W.shape[0], dtype=torch.float32, device=W.device)
+    _lib.check(
+        _lib.lib.slk_scale_minmax(
+            dev.ptr(W), W.shape[0], W.shape[1], float(codebook.min()), float(codebook.max()), dev.ptr(out), dev.stream_handle()
+        )
+    )
+    return out
+
+
+def compute_non_saturating_scaling(data, codebook, axis=0):
+    """Largest-magnitude scale with no saturation (sleekit/scaling.py:44-55)."""
+    _rows_only(data, axis)
+    return dev.like_input(_no_clip_scale(dev.to_device(data), codebook), data)
+
+
 def quantize_with_scaling(data, scale, quantizer, H=None, act_order="diag", damp=0.01, nb_ls_moves=0):
     """Quantize the weights after applying a per-row scaling factor (sleekit/scaling.py:58-81).
 
@@ -49,27 +85,105 @@ def quantize_with_scaling(data, scale, quantizer, H=None, act_order="diag", damp
     assert data.shape[0] == scale.shape[0]
     Wd, sd = dev.to_device(data), dev.to_device(scale)
     if H is None:
-        cb_abi = engine.require_uniform(quantizer)
+        engine.require_uniform(quantizer)
         q = quantizer.quantize_value(engine.rows_divide(Wd, sd))
-        del cb_abi
         return dev.like_input(engine.rows_divide(q, sd, invert=True), data)
     res = engine.quantize_layer(Wd, dev.to_device(H), quantizer, sd, act_order, damp, nb_ls_moves, want_idx=False)
     return dev.like_input(res.Q, data)
 
 
-def _next(name, where):
-    def stub(*args, **kwargs):
-        raise NotImplementedError(
-            f"{name} ({where}) is the callers' scale search, scheduled after the hot path (SURVEY.md 8f); "
-            "sleekit_amd has no CPU fallback for it"
+def _times(a, b=None, c=0.0):
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib.slk_scale_times(dev.ptr(a), dev.ptr(b), float(c), a.shape[0], dev.ptr(out), dev.stream_handle()))
+    return out
+
+
+def _search_over(W, base, factors, error_of_scale):
+    """Grid search with row errors produced by `error_of_scale(scale)` (full-Hessian and OBQ variants)."""
+    R = W.shape[0]
+    best_err = torch.empty(R, dtype=torch.float32, device=W.device)
+    best_f = torch.empty(R, dtype=torch.float32, device=W.device)
+    s = dev.stream_handle()
+    _lib.check(_lib.lib.slk_search_step(None, 0.0, R, dev.ptr(best_err), dev.ptr(best_f), 1, s))
+    for f in factors:
+        err = error_of_scale(_times(base, None, f))
+        _lib.check(_lib.lib.slk_search_step(dev.ptr(err), float(f), R, dev.ptr(best_err), dev.ptr(best_f), 0, s))
+    return _times(base, best_f)
+
+
+def compute_min_mse_scaling(data, codebook, axis=0, H=None, min_factor=0.05, max_factor=1.0, grid_size=100):
+    """Scale minimising the (Hessian-weighted) squared error of round-to-nearest (sleekit/scaling.py:98-134)."""
+    _rows_only(data, axis)
+    cb_abi = engine.require_uniform(codebook)
+    W = dev.to_device(data)
+    R, n = W.shape
+    base = _no_clip_scale(W, codebook)
+    factors = np.linspace(min_factor, max_factor, grid_size, dtype=np.float32)
+    if H is None or H.ndim == 1:
+        hd = None if H is None else dev.to_device(H)
+        if hd is not None:
+            assert hd.shape[0] == n
+        fac = torch.from_numpy(factors).to(W.device)
+        out = torch.empty(R, dtype=torch.float32, device=W.device)
+        levels, lo, hi = cb_abi
+        _lib.check(
+            _lib.lib.slk_scale_search(
+                dev.ptr(W), dev.ptr(base), dev.ptr(fac), len(factors), dev.ptr(hd), R, n, levels, lo, hi, dev.ptr(out),
+                dev.stream_handle(),
+            )
         )
+        return dev.like_input(out, data)
+    assert H.ndim == 2 and H.shape[0] == H.shape[1] == n
+    Hd = dev.to_device(H)
 
-    stub.__name__ = name
-    return stub
+    def error_of(scale):
+        q = codebook.quantize_value(engine.rows_divide(W, scale))
+        return engine.row_errors(engine.rows_divide(q, scale, invert=True), W, Hd)
+
+    return dev.like_input(_search_over(W, base, factors, error_of), data)
 
 
-compute_norm_scaling = _next("compute_norm_scaling", "sleekit/scaling.py:35-41")
-compute_non_saturating_scaling = _next("compute_non_saturating_scaling", "sleekit/scaling.py:44-55")
-compute_min_mse_scaling = _next("compute_min_mse_scaling", "sleekit/scaling.py:98-134")
-compute_obq_scaling = _next("compute_obq_scaling", "sleekit/scaling.py:137-190")
-compute_scaling = _next("compute_scaling", "sleekit/scaling.py:193-238")
+def compute_obq_scaling(data, codebook, axis, H, damp=0.01, act_order="diag", min_factor=0.05, max_factor=1.0, grid_size=100):
+    """Scale minimising the error AFTER the GPTQ loop (sleekit/scaling.py:137-190): one factor, 100 loops."""
+    _rows_only(data, axis)
+    cb_abi = engine.require_uniform(codebook)
+    W, Hd = dev.to_device(data), dev.to_device(H)
+    R, n = W.shape
+    base = _no_clip_scale(W, codebook)
+    mode = engine.order_mode_code(act_order)
+    miss = engine.column_miss(engine.rows_divide(W, base), cb_abi, mode == _lib.ORDER_SQERR) if mode >= _lib.ORDER_ERR else None
+    order, U, info = engine.factorize(Hd, n, damp, mode, miss)
+    dev.note_info(info, "compute_hessian_chol")
+    factors = np.linspace(min_factor, max_factor, grid_size, dtype=np.float32)
+
+    def error_of(scale):
+        Q, _, _ = engine.run_loop(W, scale, order, U, cb_abi, 32, 8, want_idx=False)
+        return engine.row_errors(engine.rows_divide(Q, scale, invert=True), W, Hd)
+
+    return dev.like_input(_search_over(W, base, factors, error_of), data)
+
+
+def compute_scaling(data, codebook, H, mode="mse", axis=0, min_factor=0.05, max_factor=1.0, grid_size=100):
+    """Mode dispatcher (sleekit/scaling.py:193-238)."""
+    if mode == "max":
+        return compute_non_saturating_scaling(data, codebook, axis)
+    if mode == "norm":
+        return compute_norm_scaling(data, axis)
+    kw = dict(grid_size=grid_size, min_factor=min_factor, max_factor=max_factor)
+    if mode == "obq":
+        return compute_obq_scaling(data, codebook, axis, H=H, **kw)
+    if mode == "mse":
+        H = None
+    elif mode.startswith("hessian"):
+        if len(mode) > 7:
+            Hd = dev.to_device(H).clone()
+            Hd.diagonal().add_(np.float32(0.01 * float(mode[7:])) * Hd.diagonal().mean())
+            H = Hd if dev.is_device_tensor(H) else dev.like_input(Hd, H)
+    elif mode.startswith("diag"):
+        Hd = dev.to_device(H).diagonal().contiguous()
+        if len(mode) > 4:
+            Hd = Hd + np.float32(0.01 * float(mode[4:])) * Hd.mean()
+        H = Hd if dev.is_device_tensor(H) else dev.like_input(Hd, H)
+    else:
+        raise RuntimeError(f"Unknown scaling mode {mode}")
+    return compute_min_mse_scaling(data, codebook, axis, H=H, **kw)

@@ -176,6 +176,39 @@ def pieces():
         st.add_batch(torch.from_numpy(X[a:b]).reshape(1, b - a, 48))
     P["stats/X"], P["stats/H"], P["stats/mean"] = X, st.hessian.numpy().copy(), st.mean.numpy().copy()
     P["stats/count"] = np.int64(st.count)
+
+    # --- the whole adapter: presets on a Linear layer, unfold + statistics on conv layers ---
+    def seeded_linear(n_in, n_out, seed):
+        lin = torch.nn.Linear(n_in, n_out)
+        with torch.no_grad():
+            lin.weight.copy_(torch.from_numpy(synth.make_weights(n_out, n_in, seed)))
+            lin.bias.copy_(torch.from_numpy((0.1 * synth.normal_grid(seed, 11, 1, n_out)[0]).astype(np.float32)))
+        return lin
+
+    Xa = synth.make_activations(300, 40, 2031).astype(np.float32)
+    P["adapter/X"] = Xa
+    for preset, bits in (("basic", 4), ("sleekit_light", 3), ("sleekit_heavy", 3)):
+        lin = seeded_linear(40, 24, 2032)
+        st = Sleekit(lin)
+        st.add_batch(torch.from_numpy(Xa[:128]))
+        st.add_batch(torch.from_numpy(Xa[128:]).reshape(2, 86, 40))
+        getattr(st, "quantize_" + preset)(bits)
+        P[f"adapter/{preset}/weight"] = lin.weight.detach().numpy().copy()
+        P[f"adapter/{preset}/bias"] = lin.bias.detach().numpy().copy()
+    xc2 = torch.from_numpy(synth.make_activations(4 * 6 * 7 * 7, 1, 2033).astype(np.float32).reshape(4, 6, 7, 7))
+    c2 = torch.nn.Conv2d(6, 5, 3, padding=1, stride=2)
+    st = Sleekit(c2)
+    st.add_batch(xc2)
+    st.add_batch(xc2[0])
+    P["adapter/conv2d/x"], P["adapter/conv2d/H"], P["adapter/conv2d/mean"] = xc2.numpy(), st.hessian.numpy().copy(), st.mean.numpy().copy()
+    P["adapter/conv2d/count"] = np.int64(st.count)
+    xc1 = torch.from_numpy(synth.make_activations(3 * 6 * 11, 1, 2034).astype(np.float32).reshape(3, 6, 11))
+    c1 = torch.nn.Conv1d(6, 5, 3, dilation=2)
+    st = Sleekit(c1)
+    st.add_batch(xc1)
+    st.add_batch(xc1[1])
+    P["adapter/conv1d/x"], P["adapter/conv1d/H"], P["adapter/conv1d/mean"] = xc1.numpy(), st.hessian.numpy().copy(), st.mean.numpy().copy()
+    P["adapter/conv1d/count"] = np.int64(st.count)
     return P
 
 

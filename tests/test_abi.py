@@ -68,6 +68,7 @@ def test_product_has_no_cpu_path():
     W = np.zeros((4, 8), np.float32)
     H = np.eye(8, dtype=np.float32)
     for call in (
+        lambda: scaling.compute_min_mse_scaling(W, cb),
         lambda: cb(W),
         lambda: obq.quantize_opt(W, H, cb),
         lambda: scaling.quantize_with_scaling(W, np.ones(4, np.float32), cb, H),

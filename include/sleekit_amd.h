@@ -112,6 +112,16 @@ int slk_factor_load(const double *M, int n, double *A, slk_stream_t stream);
 int slk_chol_inverse_upper(double *A, int n, double *U, int *info, void *workspace,
                            size_t ws_bytes, slk_stream_t stream);
 
+/* Multi-GPU payload of one layer's factor: one buffer of 8-byte words,
+ *   [0] status word, [1..n] order, then the upper triangle of U row by row,
+ * slk_factor_payload_words(n) = n (n + 1) / 2 + n + 1 words -- what the single RCCL broadcast per
+ * layer carries.  Unpack restores the square U (zeros below the diagonal).   */
+size_t slk_factor_payload_words(int n);
+int slk_factor_pack(const double *U, const long long *order, const int *info, int n, void *payload,
+                    slk_stream_t stream);
+int slk_factor_unpack(const void *payload, int n, double *U, long long *order, int *info,
+                      slk_stream_t stream);
+
 /* a5+a8+a9+a10  quantize_opt without local search  (sleekit/obq.py:106-137, 202-213)
  *     W: R x n float32.  scale: per-row divisor applied on load (NULL: W is used as is).
  *     Runs the blocked column-sequential loop in the order `order` with factor U and

@@ -213,6 +213,40 @@ __global__ __launch_bounds__(256) void k_load_reversed(const double *__restrict_
     }
 }
 
+// ------------------------------------------------------------------ factor payload (multi-GPU)
+// One 8-byte-word buffer per layer travels over xGMI:  [0] status, [1 .. n] order,
+// then the upper triangle of U row by row (row i: n - i doubles).  n (n + 1) / 2 + n + 1 words,
+// half of what the square matrix would cost.
+__device__ __forceinline__ size_t tri_offset(size_t i, size_t n) { return i * n - i * (i - 1) / 2; }
+
+__global__ __launch_bounds__(256) void k_pack_factor(const double *__restrict__ U, const long long *__restrict__ order,
+                                                     const int *__restrict__ info, int n, long long *__restrict__ payload) {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) payload[0] = info[0];
+        for (int j = threadIdx.x; j < n; j += blockDim.x) payload[1 + j] = order[j];
+    }
+    double *tri = reinterpret_cast<double *>(payload + 1 + n);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const double *src = U + (size_t)i * n;
+        double *dst = tri + tri_offset(i, n) - i;  // dst[j] for j >= i
+        for (int j = i + threadIdx.x; j < n; j += blockDim.x) dst[j] = src[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unpack_factor(const long long *__restrict__ payload, int n, double *__restrict__ U,
+                                                       long long *__restrict__ order, int *__restrict__ info) {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) info[0] = (int)payload[0];
+        for (int j = threadIdx.x; j < n; j += blockDim.x) order[j] = payload[1 + j];
+    }
+    const double *tri = reinterpret_cast<const double *>(payload + 1 + n);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        double *dst = U + (size_t)i * n;
+        const double *src = tri + tri_offset(i, n) - i;
+        for (int j = threadIdx.x; j < n; j += blockDim.x) dst[j] = (j >= i) ? src[j] : 0.0;
+    }
+}
+
 }  // namespace slk
 
 using namespace slk;
@@ -226,6 +260,24 @@ int slk_factor_load(const double *M, int n, double *A, slk_stream_t stream) {
     const int ld = slk_factor_ld(n);
     hipStream_t s = as_stream(stream);
     SLK_RUN("factor_load", 0, 4.0 * n * n + 8.0 * ld * ld, s, k_load_reversed<<<ld < 2048 ? ld : 2048, 256, 0, s>>>(M, n, ld, A));
+    return SLK_OK;
+}
+
+size_t slk_factor_payload_words(int n) { return n <= 0 ? 0 : (size_t)n * ((size_t)n + 1) / 2 + (size_t)n + 1; }
+
+int slk_factor_pack(const double *U, const long long *order, const int *info, int n, void *payload, slk_stream_t stream) {
+    SLK_REQUIRE(U && order && info && payload && n > 0, "bad arguments");
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("factor_pack", 0, 8.0 * n * (n + 1.0), s,
+            k_pack_factor<<<n < 2048 ? n : 2048, 256, 0, s>>>(U, order, info, n, static_cast<long long *>(payload)));
+    return SLK_OK;
+}
+
+int slk_factor_unpack(const void *payload, int n, double *U, long long *order, int *info, slk_stream_t stream) {
+    SLK_REQUIRE(U && order && info && payload && n > 0, "bad arguments");
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("factor_unpack", 0, 4.0 * n * (n + 1.0) + 8.0 * n * n, s,
+            k_unpack_factor<<<n < 2048 ? n : 2048, 256, 0, s>>>(static_cast<const long long *>(payload), n, U, order, info));
     return SLK_OK;
 }
 

@@ -55,12 +55,31 @@ class HipBackend:
                              [torch.cuda.Stream() for _ in range(nl)])
         return self._streams
 
-    def alloc_factor(self, n, device):
-        return (
-            torch.empty(n, dtype=torch.int64, device=device),
-            torch.empty((n, n), dtype=torch.float64, device=device),
-            torch.empty(1, dtype=torch.int32, device=device),
-        )
+    def alloc_payload(self, n, device):
+        from . import _lib
+
+        return torch.empty(int(_lib.lib.slk_factor_payload_words(n)), dtype=torch.int64, device=device)
+
+    def pack(self, factor):
+        """(order, U, info) -> one int64-word buffer: status, order, packed upper triangle of U."""
+        from . import _device as dev
+        from . import _lib
+
+        order, U, info = factor
+        n = U.shape[0]
+        payload = self.alloc_payload(n, U.device)
+        _lib.check(_lib.lib.slk_factor_pack(dev.ptr(U), dev.ptr(order), dev.ptr(info), n, dev.ptr(payload), dev.stream_handle()))
+        return payload
+
+    def unpack(self, payload, n):
+        from . import _device as dev
+        from . import _lib
+
+        order = torch.empty(n, dtype=torch.int64, device=payload.device)
+        U = torch.empty((n, n), dtype=torch.float64, device=payload.device)
+        info = torch.empty(1, dtype=torch.int32, device=payload.device)
+        _lib.check(_lib.lib.slk_factor_unpack(dev.ptr(payload), n, dev.ptr(U), dev.ptr(order), dev.ptr(info), dev.stream_handle()))
+        return order, U, info
 
     def factorize(self, layer):
         eng = self.engine
@@ -126,20 +145,25 @@ def quantize_stream(layers, backend, comm_device=None):
             if side:
                 ready[l] = torch.cuda.Event()
                 ready[l].record(fs)
-    # 2. one asynchronous broadcast per layer from its root, issued in layer order
+    # 2. ONE asynchronous broadcast per layer from its root, issued in layer order: the root packs
+    #    (status, order, upper triangle of U) into a single buffer, the others unpack it
     pending = [None] * n_layers
+    payloads = [None] * n_layers
     if size > 1:
         if cstream is not None:
             cstream.wait_stream(here)
         with on(cstream):
             for l in range(n_layers):
                 root = factor_root(l, size)
-                if root != rank:
-                    dev = comm_device if comm_device is not None else layers[l]["H"].device
-                    factors[l] = backend.alloc_factor(layers[l]["H"].shape[0], dev)
-                elif ready[l] is not None:
-                    cstream.wait_event(ready[l])
-                pending[l] = [dist.broadcast(t, src=root, async_op=True) for t in factors[l]]
+                n = layers[l]["H"].shape[0]
+                if root == rank:
+                    if ready[l] is not None:
+                        cstream.wait_event(ready[l])
+                    payloads[l] = backend.pack(factors[l])
+                else:
+                    dev_ = comm_device if comm_device is not None else layers[l]["H"].device
+                    payloads[l] = backend.alloc_payload(n, dev_)
+                pending[l] = dist.broadcast(payloads[l], src=root, async_op=True)
     # 3. every rank runs its rows of every layer as the factors land (loops of consecutive layers
     #    alternate between streams too: their leaf chains are latency-bound as well)
     out = []
@@ -149,8 +173,9 @@ def quantize_stream(layers, backend, comm_device=None):
             ls.wait_stream(here)
         with on(ls):
             if pending[l] is not None:
-                for work in pending[l]:
-                    work.wait()  # orders the stream behind the transfer; no host block on GPU
+                pending[l].wait()  # orders the stream behind the transfer; no host block on GPU
+                if factors[l] is None:
+                    factors[l] = backend.unpack(payloads[l], layer["H"].shape[0])
             elif ready[l] is not None:
                 ls.wait_event(ready[l])
             lo, hi = row_range(layer["W"].shape[0], rank, size)
@@ -161,7 +186,7 @@ def quantize_stream(layers, backend, comm_device=None):
         for st in lstreams:
             here.wait_stream(st)
         # tensors made on the side streams are consumed on the caller's stream: keep the allocator honest
-        for f in factors:
+        for f in factors + [(p,) for p in payloads if p is not None]:
             for t in f:
                 t.record_stream(here)
         for shard in out:

@@ -23,8 +23,15 @@ class FakeBackend:
     def __init__(self):
         self.factored = []
 
-    def alloc_factor(self, n, device):
-        return (torch.empty(n, dtype=torch.int64), torch.empty((n, n), dtype=torch.float64), torch.empty(1, dtype=torch.int32))
+    def alloc_payload(self, n, device):
+        return torch.empty(1 + n + n * n, dtype=torch.int64)
+
+    def pack(self, factor):
+        order, U, info = factor
+        return torch.cat([info.long(), order, U.reshape(-1).view(torch.int64)])
+
+    def unpack(self, payload, n):
+        return payload[1 : 1 + n].clone(), payload[1 + n :].view(torch.float64).reshape(n, n).clone(), payload[:1].int()
 
     def factorize(self, layer):
         n = layer["H"].shape[0]

@@ -180,6 +180,8 @@ int slk_diag_mean(const float *H, int n, float *out, void *workspace, size_t ws_
  * v_mfma_f64_16x16x4_f64 (2048 flop each) / v_mfma_f32_32x32x2_f32 (4096 flop each).      */
 int slk_probe_mfma_f64(double *sink, int blocks, int iters, slk_stream_t stream);
 int slk_probe_mfma_f32(float *sink, int blocks, int iters, slk_stream_t stream);
+/* float64 probe with `nacc` (8 or 16) independent accumulators per wave: iters x nacc MFMAs per wave. */
+int slk_probe_mfma_f64_acc(double *sink, int blocks, int iters, int nacc, slk_stream_t stream);
 /* One wave runs `iters` steps of a dependent chain (mode 0: fma f64, 1: 8 independent fma f64,
  * 2: fma f32, 3: rsq f64, 4: divide f64, 5: divide f32, 6: f64->f32->f64 + mul);
  * out[0] = shader cycles, out[1] = 100 MHz ticks, out[2] = checksum.                      */

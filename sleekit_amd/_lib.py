@@ -59,6 +59,7 @@ PROTOTYPES = {
     "slk_diag_mean": (c_int, [P, c_int, P, P, c_size_t, P]),
     "slk_probe_mfma_f64": (c_int, [P, c_int, c_int, P]),
     "slk_probe_mfma_f32": (c_int, [P, c_int, c_int, P]),
+    "slk_probe_mfma_f64_acc": (c_int, [P, c_int, c_int, c_int, P]),
     "slk_probe_chain": (c_int, [P, c_int, c_int, P]),
     "slk_profile_enable": (c_int, [c_int]),
     "slk_profile_reset": (c_int, []),

@@ -17,6 +17,27 @@ __global__ __launch_bounds__(256) void k_probe_f64(double *sink, int iters) {
     if (s[0] + s[1] + s[2] + s[3] == 12345.678) sink[0] = s[0];  // keep the chain alive
 }
 
+// Same probe with 8 or 16 independent accumulators per wave and distinct operands per MFMA.
+template <int NACC>
+__global__ __launch_bounds__(256) void k_probe_f64_n(double *sink, int iters) {
+    double4_t c[NACC];
+    double a[NACC], b[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        c[i] = (double4_t){0, 0, 0, 0};
+        a[i] = 1.0 + (threadIdx.x + i) * 1e-3;
+        b[i] = 1.0 - (threadIdx.x + 3 * i) * 1e-3;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[(i + 1) % NACC], c[i], 0, 0, 0);
+    }
+    double4_t s = c[0];
+#pragma unroll
+    for (int i = 1; i < NACC; ++i) s += c[i];
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678) sink[0] = s[0];
+}
+
 __global__ __launch_bounds__(256) void k_probe_f32(float *sink, int iters) {
     float16_t c0, c1, c2, c3;
     for (int r = 0; r < 16; ++r) c0[r] = c1[r] = c2[r] = c3[r] = 0.0f;
@@ -93,7 +114,7 @@ size_t slk_workspace_bytes(int R, int n) {
     const size_t rn = (size_t)(R > 0 ? R : 1) * (size_t)n;
     size_t factor = 2 * ld * ld * sizeof(double);                      // X and S of slk_chol_inverse_upper
     size_t loop = 2 * rn * sizeof(float) + (size_t)n * sizeof(int);    // permuted Q and E, inverse order
-    size_t search = rn * sizeof(float) + (size_t)(R + n) * sizeof(float) + (size_t)R * ((n + 127) / 128) * sizeof(float);
+    size_t search = rn * sizeof(float) + (size_t)(R + n) * sizeof(float) + (size_t)R * ((n + 127) / 128) * sizeof(float) + 4096;
     size_t prep = 64 * sizeof(float) + (size_t)n * (sizeof(double) + 1);
     size_t m = factor;
     if (loop > m) m = loop;
@@ -106,6 +127,16 @@ int slk_probe_mfma_f64(double *sink, int blocks, int iters, slk_stream_t stream)
     SLK_REQUIRE(sink && blocks > 0 && iters > 0, "bad arguments");
     hipStream_t s = as_stream(stream);
     SLK_RUN("probe_mfma_f64", 4.0 * 2048 * 4 * iters * blocks, 0, s, k_probe_f64<<<blocks, 256, 0, s>>>(sink, iters));
+    return SLK_OK;
+}
+
+int slk_probe_mfma_f64_acc(double *sink, int blocks, int iters, int nacc, slk_stream_t stream) {
+    SLK_REQUIRE(sink && blocks > 0 && iters > 0 && (nacc == 8 || nacc == 16), "bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (nacc == 8)
+        SLK_RUN("probe_mfma_f64", 8.0 * 2048 * 4 * iters * blocks, 0, s, k_probe_f64_n<8><<<blocks, 256, 0, s>>>(sink, iters));
+    else
+        SLK_RUN("probe_mfma_f64", 16.0 * 2048 * 4 * iters * blocks, 0, s, k_probe_f64_n<16><<<blocks, 256, 0, s>>>(sink, iters));
     return SLK_OK;
 }
 

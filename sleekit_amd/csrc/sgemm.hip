@@ -2,6 +2,8 @@
 //   a11  channelwise_error (sleekit/obq.py:89-95): row_err = rowsum(((W-Q) @ H) * (W-Q))
 //   a1   Sleekit.add_batch (sleekit/statistics.py:76-87): H = H f + X^T X / c'
 // Both are dense contractions on v_mfma_f32_32x32x2_f32 through mfma32.h.
+#include <stdlib.h>
+
 #include "mfma32.h"
 
 namespace slk {
@@ -14,30 +16,70 @@ namespace slk {
 __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W, const float *__restrict__ Q,
                                                      const float *__restrict__ H, int R, int n,
                                                      float *__restrict__ G, float *__restrict__ partial,
-                                                     int n_tiles, int vec_ok) {
+                                                     int n_tiles, int vec_ok, const int *__restrict__ sym_flag) {
     __shared__ Tile128Smem sm;
     __shared__ float rowpart[2][T32];
-    const int r0 = blockIdx.y * T32, j0 = blockIdx.x * T32;
+    // Column tiles are rotated by the row-tile index: with the symmetric shortcut below a tile's
+    // depth grows with its column, and blocks id, id + 256, ... (same CU) must not all be deep.
+    const int tile_x = (blockIdx.x + blockIdx.y) % n_tiles;
+    const int r0 = blockIdx.y * T32, j0 = tile_x * T32;
     const int t = threadIdx.x;
     Acc128 acc;
     acc.zero();
-    const int kend = (n + K32 - 1) / K32 * K32;
+    const int kfull = (n + K32 - 1) / K32 * K32;
+    // H symmetric (checked bit-wise on the device) and G not wanted:
+    //   sum_k D_k H_kj over all k  ==  2 * sum_{k < j0} + the 128-wide diagonal band, after the
+    //   final multiplication by D_j and the sum over j.  Halves the flops of the layer error.
+    const bool sym = sym_flag != nullptr && sym_flag[0] != 0;
+    const int kend = sym ? min(j0 + T32, kfull) : kfull;
+    const int ksplit = sym ? j0 : 0;  // [0, ksplit) counted twice
     const int a_row = r0 + (t >> 1), a_k = (t & 1) * 8;  // A: D = W - Q, K contiguous
     const int b_k = t >> 4, b_col = j0 + (t & 15) * 8;   // B: H, columns contiguous
-    if (vec_ok && r0 + T32 <= R && j0 + T32 <= n && kend == n) {
+    auto twice = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.c[i][j][r] = acc.c[i][j][r] * 2.0f;
+    };
+    if (vec_ok && r0 + T32 <= R && j0 + T32 <= n && kfull == n) {
         // interior tile: unconditional 16-byte loads
         const float *pw = W + (size_t)a_row * n + a_k, *pq = Q + (size_t)a_row * n + a_k;
         const float *ph = H + (size_t)b_k * n + b_col;
-        tile128_mac<true, true>(
-            acc, sm, 0, kend,
-            [&](int k0, float(&v)[8]) {
-                float w[8], q[8];
-                load8<true>(pw + k0, w);
-                load8<true>(pq + k0, q);
+        auto la = [&](int k0, float(&v)[8]) {
+            float w[8], q[8];
+            load8<true>(pw + k0, w);
+            load8<true>(pq + k0, q);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = w[e] - q[e];
-            },
-            [&](int k0, float(&v)[8]) { load8<true>(ph + (size_t)k0 * n, v); });
+            for (int e = 0; e < 8; ++e) v[e] = w[e] - q[e];
+        };
+        auto lb = [&](int k0, float(&v)[8]) { load8<true>(ph + (size_t)k0 * n, v); };
+        if (ksplit > 0) {
+            tile128_mac<true, true>(acc, sm, 0, ksplit, la, lb);
+            twice();
+            __syncthreads();
+        }
+        tile128_mac<true, true>(acc, sm, ksplit, kend, la, lb);
+    } else if (ksplit > 0) {
+        const bool row_ok = a_row < R;
+        const size_t arow = (size_t)min(a_row, R - 1) * n;
+        auto la = [&](int k0, float(&v)[8]) {
+            const int k = min(k0 + a_k, n - 1), last = n - 1 - (k0 + a_k);
+            float w[8], q[8];
+            load8_guarded(W + arow + k, last, row_ok, w);
+            load8_guarded(Q + arow + k, last, row_ok, q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = w[e] - q[e];
+        };
+        auto lb = [&](int k0, float(&v)[8]) {
+            const int k = k0 + b_k;
+            load8_guarded(H + (size_t)min(k, n - 1) * n + min(b_col, n - 1), n - 1 - b_col, k < n, v);
+        };
+        tile128_mac<true, true>(acc, sm, 0, ksplit, la, lb);
+        twice();
+        __syncthreads();
+        tile128_mac<true, true>(acc, sm, ksplit, kend, la, lb);
     } else {
         const bool row_ok = a_row < R;
         const size_t arow = (size_t)min(a_row, R - 1) * n;
@@ -83,8 +125,29 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
     }
     __syncthreads();
     if (threadIdx.x < T32 && r0 + threadIdx.x < R)
-        partial[(size_t)(r0 + threadIdx.x) * n_tiles + blockIdx.x] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
+        partial[(size_t)(r0 + threadIdx.x) * n_tiles + tile_x] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
 }
+
+// flag[0] = 1 iff H is bit-wise symmetric (flag must be preset to 1).
+__global__ __launch_bounds__(256) void k_symmetry_flag(const float *__restrict__ H, int n, int *__restrict__ flag) {
+    __shared__ float tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    bool ok = true;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = bj * 32 + r, j = bi * 32 + tx;  // the mirrored tile, read row-wise
+        tile[r][tx] = (i < n && j < n) ? H[(size_t)i * n + j] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = bi * 32 + r, j = bj * 32 + tx;
+        if (i < n && j < n) ok = ok && (__float_as_int(H[(size_t)i * n + j]) == __float_as_int(tile[tx][r]));
+    }
+    if (!ok) flag[0] = 0;
+}
+
+__global__ void k_set_flag(int *flag, int v) { flag[0] = v; }
 
 __global__ __launch_bounds__(256) void k_error_reduce(const float *__restrict__ partial, int R, int n_tiles,
                                                       float *__restrict__ row_err) {
@@ -157,15 +220,23 @@ int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n,
     const int n_tiles = (n + T32 - 1) / T32;
     Arena ws(workspace, ws_bytes);
     float *partial = ws.take<float>((size_t)R * n_tiles);
-    if (!partial) {
+    int *sym = ws.take<int>(64);
+    if (!partial || !sym) {
         set_error("workspace too small");
         return SLK_E_WS;
     }
     hipStream_t s = as_stream(stream);
     dim3 grid(n_tiles, (R + T32 - 1) / T32);
     const int vec_ok = n % 4 == 0 && ((uintptr_t)W | (uintptr_t)Q | (uintptr_t)H) % 16 == 0;
+    const bool try_sym = G == nullptr && getenv("SLK_NO_SYM_ERROR") == nullptr;
+    if (try_sym) {
+        SLK_RUN("set_flag", 0, 4, s, k_set_flag<<<1, 1, 0, s>>>(sym, 1));
+        const int t32 = (n + 31) / 32;
+        SLK_RUN("symmetry_check", 0, 4.0 * n * n, s, k_symmetry_flag<<<dim3(t32, t32), 256, 0, s>>>(H, n, sym));
+    }
+    // algorithmic flops: the definition (2 R n^2) whichever way they are obtained
     SLK_RUN("error_gemm", 2.0 * R * n * n, 8.0 * R * n + 4.0 * n * n + (G ? 4.0 * R * n : 0.0), s,
-            k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles, vec_ok));
+            k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles, vec_ok, try_sym ? sym : nullptr));
     SLK_RUN("error_reduce", 0, 4.0 * R * n_tiles, s, k_error_reduce<<<(R + 255) / 256, 256, 0, s>>>(partial, R, n_tiles, row_err));
     return SLK_OK;
 }

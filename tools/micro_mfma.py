@@ -15,3 +15,12 @@ for blocks in (256, 512, 1024, 2048):
         ms = t0.elapsed_time(t1)
         total = blocks * 4 * iters * 4 * flop
         print(f"{name}  blocks={blocks:5d}: {total/ms/1e9:8.2f} TFLOP/s  ({ms:.3f} ms)")
+
+for nacc in (8, 16):
+    for blocks in (256, 512, 1024, 2048):
+        iters = 2000
+        _lib.lib.slk_probe_mfma_f64_acc(sink64.data_ptr(), blocks, iters, nacc, None); torch.cuda.synchronize()
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record(); _lib.lib.slk_probe_mfma_f64_acc(sink64.data_ptr(), blocks, iters, nacc, None); t1.record(); torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1)
+        print(f"f64 16x16x4 {nacc} accumulators blocks={blocks:5d}: {blocks*4*iters*nacc*2048/ms/1e9:8.2f} TFLOP/s ({ms:.3f} ms)")

@@ -4,12 +4,13 @@ Given the shared factor U, every output row of W goes through the loop, the loca
 and the error on its own (sleekit/obq.py:106-137, 264-346, 89-95 have no cross-row term),
 so the path shards by rows with no data-path collective.  What does NOT shard is the
 n x n factorisation; over a stream of layers it is spread instead: rank (l mod G) factors
-layer l and broadcasts (order, U, status) once -- one RCCL broadcast per layer over xGMI --
+layer l and its packed factor (status, order, upper triangle of U) crosses xGMI exactly once,
 while every rank runs rows [r R/G, (r+1) R/G) of every layer.
 
 One process per GPU; `torch.distributed` must be initialised by the caller (backend "nccl"
-is RCCL on ROCm).  The broadcasts are issued asynchronously up front, so layer l's loop
-overlaps the transfer of layer l+1's factor; on a single rank nothing is communicated.
+is RCCL on ROCm).  The exchange is one asynchronous all-gather per round of G layers (G
+simultaneous broadcasts, one root each), issued up front so the loops of round g overlap the
+factorisations and the transfer of round g+1; on a single rank nothing is communicated.
 
 The module is engine-agnostic: `backend` supplies factorize / run_rows, which lets the CPU
 test-suite drive the same scheduling code over gloo with a stand-in backend.
@@ -55,19 +56,23 @@ class HipBackend:
                              [torch.cuda.Stream() for _ in range(nl)])
         return self._streams
 
-    def alloc_payload(self, n, device):
+    def payload_words(self, n):
         from . import _lib
 
-        return torch.empty(int(_lib.lib.slk_factor_payload_words(n)), dtype=torch.int64, device=device)
+        return int(_lib.lib.slk_factor_payload_words(n))
 
-    def pack(self, factor):
-        """(order, U, info) -> one int64-word buffer: status, order, packed upper triangle of U."""
+    def alloc_payload(self, words, device):
+        return torch.empty(words, dtype=torch.int64, device=device)
+
+    def pack(self, factor, words):
+        """(order, U, info) -> the first payload_words(n) of a `words`-long int64 buffer:
+        status, order, packed upper triangle of U."""
         from . import _device as dev
         from . import _lib
 
         order, U, info = factor
         n = U.shape[0]
-        payload = self.alloc_payload(n, U.device)
+        payload = self.alloc_payload(words, U.device)
         _lib.check(_lib.lib.slk_factor_pack(dev.ptr(U), dev.ptr(order), dev.ptr(info), n, dev.ptr(payload), dev.stream_handle()))
         return payload
 
@@ -109,6 +114,16 @@ class _NullCtx:
         return False
 
 
+def _all_gather_words(payload, size):
+    """All-gather equal-sized int64 buffers; returns (list of per-rank views, async work)."""
+    if dist.get_backend() == "nccl":
+        out = torch.empty(size * payload.numel(), dtype=payload.dtype, device=payload.device)
+        work = dist.all_gather_into_tensor(out, payload, async_op=True)
+        return list(out.chunk(size)), work
+    outs = [torch.empty_like(payload) for _ in range(size)]
+    return outs, dist.all_gather(outs, payload, async_op=True)
+
+
 def quantize_stream(layers, backend, comm_device=None):
     """Quantize `layers` (list of dicts with W (R, n), H (n, n), optional scale (R,)) across the ranks.
 
@@ -116,14 +131,21 @@ def quantize_stream(layers, backend, comm_device=None):
     Every rank holds every layer's inputs (W, H are inputs of the path and resident before
     it starts); only the factor travels.
 
-    Three queues per rank when the backend provides device streams (`backend.streams()`):
-      factor stream : the n x n factorisations this rank owns, back to back
-      comm stream   : one broadcast per layer, each behind its factor's event
-      main stream   : the row loops, each behind its layer's factor / broadcast
-    so the latency-bound factorisation of layer l+1 runs under the loop and error of layer l.
+    Layers are taken in ROUNDS of G (= world size): in round g rank r factors layer g G + r, then
+    ONE collective per round exchanges the packed factors (status, order, upper triangle of U:
+    n (n + 1) / 2 + n + 1 words per layer).  It is an all-gather -- G simultaneous one-to-all
+    broadcasts -- because xGMI is a point-to-point mesh: every rank then receives over all of its
+    7 links at once, where G separate ring broadcasts would each crawl through one link per hop.
+
+    Three kinds of queues per rank when the backend provides device streams (`backend.streams()`):
+      factor streams : the n x n factorisations this rank owns (latency-bound chains)
+      comm stream    : pack + all-gather of each round, behind that round's factor event
+      loop streams   : the row loops, each behind its round's collective
+    so the factorisation of round g+1 runs under the loops and errors of round g.
     """
     rank, size = world()
     n_layers = len(layers)
+    n_rounds = (n_layers + size - 1) // size
     factors = [None] * n_layers
     ready = [None] * n_layers
     fstreams, cstream, lstreams = backend.streams() if hasattr(backend, "streams") else (None, None, None)
@@ -145,25 +167,27 @@ def quantize_stream(layers, backend, comm_device=None):
             if side:
                 ready[l] = torch.cuda.Event()
                 ready[l].record(fs)
-    # 2. ONE asynchronous broadcast per layer from its root, issued in layer order: the root packs
-    #    (status, order, upper triangle of U) into a single buffer, the others unpack it
-    pending = [None] * n_layers
-    payloads = [None] * n_layers
+    # 2. one asynchronous all-gather per round, issued in round order
+    gathered = [None] * n_rounds  # (per-rank payloads, work)
+    keep = []
     if size > 1:
         if cstream is not None:
             cstream.wait_stream(here)
         with on(cstream):
-            for l in range(n_layers):
-                root = factor_root(l, size)
-                n = layers[l]["H"].shape[0]
-                if root == rank:
+            for g in range(n_rounds):
+                l = g * size + rank
+                # equal-sized contributions: pad to the widest layer of the round
+                words = max(backend.payload_words(layers[j]["H"].shape[0])
+                            for j in range(g * size, min((g + 1) * size, n_layers)))
+                if l < n_layers:
                     if ready[l] is not None:
                         cstream.wait_event(ready[l])
-                    payloads[l] = backend.pack(factors[l])
-                else:
-                    dev_ = comm_device if comm_device is not None else layers[l]["H"].device
-                    payloads[l] = backend.alloc_payload(n, dev_)
-                pending[l] = dist.broadcast(payloads[l], src=root, async_op=True)
+                    payload = backend.pack(factors[l], words)
+                else:  # no layer for this rank in the last round: contribute a blank
+                    dev_ = comm_device if comm_device is not None else layers[0]["H"].device
+                    payload = backend.alloc_payload(words, dev_).zero_()
+                gathered[g] = _all_gather_words(payload, size)
+                keep.append(payload)
     # 3. every rank runs its rows of every layer as the factors land (loops of consecutive layers
     #    alternate between streams too: their leaf chains are latency-bound as well)
     out = []
@@ -172,10 +196,11 @@ def quantize_stream(layers, backend, comm_device=None):
         if side and l < len(lstreams):
             ls.wait_stream(here)
         with on(ls):
-            if pending[l] is not None:
-                pending[l].wait()  # orders the stream behind the transfer; no host block on GPU
+            if size > 1:
+                parts, work = gathered[l // size]
+                work.wait()  # orders the stream behind the transfer; no host block on GPU
                 if factors[l] is None:
-                    factors[l] = backend.unpack(payloads[l], layer["H"].shape[0])
+                    factors[l] = backend.unpack(parts[l % size], layer["H"].shape[0])
             elif ready[l] is not None:
                 ls.wait_event(ready[l])
             lo, hi = row_range(layer["W"].shape[0], rank, size)
@@ -186,7 +211,8 @@ def quantize_stream(layers, backend, comm_device=None):
         for st in lstreams:
             here.wait_stream(st)
         # tensors made on the side streams are consumed on the caller's stream: keep the allocator honest
-        for f in factors + [(p,) for p in payloads if p is not None]:
+        extra = [(p,) for p in keep] + [tuple(g[0]) for g in gathered if g is not None]
+        for f in factors + extra:
             for t in f:
                 t.record_stream(here)
         for shard in out:

@@ -23,15 +23,19 @@ class FakeBackend:
     def __init__(self):
         self.factored = []
 
-    def alloc_payload(self, n, device):
-        return torch.empty(1 + n + n * n, dtype=torch.int64)
+    def payload_words(self, n):
+        return 1 + n + n * n
 
-    def pack(self, factor):
+    def alloc_payload(self, words, device):
+        return torch.empty(words, dtype=torch.int64)
+
+    def pack(self, factor, words):
         order, U, info = factor
-        return torch.cat([info.long(), order, U.reshape(-1).view(torch.int64)])
+        body = torch.cat([info.long(), order, U.reshape(-1).view(torch.int64)])
+        return torch.cat([body, torch.zeros(words - body.numel(), dtype=torch.int64)])
 
     def unpack(self, payload, n):
-        return payload[1 : 1 + n].clone(), payload[1 + n :].view(torch.float64).reshape(n, n).clone(), payload[:1].int()
+        return payload[1 : 1 + n].clone(), payload[1 + n : 1 + n + n * n].view(torch.float64).reshape(n, n).clone(), payload[:1].int()
 
     def factorize(self, layer):
         n = layer["H"].shape[0]

@@ -47,6 +47,8 @@ extern "C" {
 #define SLK_ORDER_DIAG 1
 #define SLK_ORDER_ERR 2   /* needs `miss` = column sums of |q(W) - W|   */
 #define SLK_ORDER_SQERR 3 /* needs `miss` = column sums of (q(W) - W)^2 */
+#define SLK_ORDER_KEYS 4  /* `miss` is reinterpreted as n float64 sort keys (ascending), e.g. from
+                             slk_inverse_diag_keys for the inv_diag / combined_diag orders       */
 
 typedef void *slk_stream_t;
 
@@ -98,6 +100,11 @@ int slk_column_miss(const float *W, int R, int n, int levels, double lo, double 
 int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const float *miss,
                         long long *order_out, double *A, void *workspace, size_t ws_bytes,
                         slk_stream_t stream);
+/* Sort keys of the orders that need diag(Hd^-1) (sleekit/obq.py:70-75): given the factor U of the
+ * damped Hessian in its ORIGINAL order (order_mode NONE), keys[j] = diag(Hd^-1)[j] = sum_i U[i][j]^2
+ * (combined == 0, "inv_diag") or -diag(Hd)[j] / diag(Hd^-1)[j] (combined != 0, "combined_diag").  */
+int slk_inverse_diag_keys(const double *U, const float *H, int n, float damp, int combined, double *keys,
+                          void *workspace, size_t ws_bytes, slk_stream_t stream);
 /* Leading dimension (and row count) of the padded float64 matrices A / scratch. */
 int slk_factor_ld(int n);
 /* Same layout from a float64 matrix as is (no damping, no order): A = reversed lower

@@ -7,7 +7,7 @@ Restates the hot path of the reference `sleekit/obq.py`:
     strip_input_mean      obq.py:14-25    (remove_input_bias)
     patch_dead_columns    obq.py:28-35    (remove_dead_values)
     inverse_factor_upper  obq.py:38-55    (compute_hessian_chol)
-    column_order          obq.py:58-86    (compute_hessian_order; diag/err/sqerr/none)
+    column_order          obq.py:58-86    (compute_hessian_order; all modes but pivot)
     row_errors/mean_error obq.py:89-103   (channelwise_error/quantization_error)
     block_schedule        obq.py:121-137  (the recursion of _quantize_opt_block, flattened)
     run_schedule          obq.py:106-137  (_quantize_opt_core + block updates)
@@ -84,6 +84,10 @@ def column_order(W, H, grid, mode, ties="numpy"):
     if mode == "sqerr":
         miss = np.square(grid(W) - W).sum(axis=0)
         return (-H.diagonal() * miss).argsort(kind=kind)
+    if mode == "combined_diag":  # obq.py:70-72
+        return (-H.diagonal() / np.linalg.inv(H).diagonal()).argsort(kind=kind)
+    if mode == "inv_diag":  # obq.py:73-75
+        return np.linalg.inv(H).diagonal().argsort(kind=kind)
     raise RuntimeError(f"Invalid act_order value {mode}")
 
 

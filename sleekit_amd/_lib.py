@@ -21,7 +21,7 @@ lib = ctypes.CDLL(LIB_PATH)
 
 OK, E_ARG, E_NOT_PD, E_HIP, E_WS = 0, -1, -2, -3, -4
 CB_VALUE, CB_INDEX, CB_UP, CB_DOWN = 0, 1, 2, 3
-ORDER_NONE, ORDER_DIAG, ORDER_ERR, ORDER_SQERR = 0, 1, 2, 3
+ORDER_NONE, ORDER_DIAG, ORDER_ERR, ORDER_SQERR, ORDER_KEYS = 0, 1, 2, 3, 4
 ORDER_MODES = {"none": ORDER_NONE, "diag": ORDER_DIAG, "err": ORDER_ERR, "sqerr": ORDER_SQERR}
 
 P = c_void_p  # device pointers travel as plain addresses
@@ -39,6 +39,7 @@ PROTOTYPES = {
     "slk_hessian_accumulate": (c_int, [P, P, P, c_int, c_int, c_longlong, P]),
     "slk_column_miss": (c_int, [P, c_int, c_int, c_int, c_double, c_double, c_int, P, P]),
     "slk_hessian_prepare": (c_int, [P, c_int, c_float, c_int, P, P, P, P, c_size_t, P]),
+    "slk_inverse_diag_keys": (c_int, [P, P, c_int, c_float, c_int, P, P, c_size_t, P]),
     "slk_factor_ld": (c_int, [c_int]),
     "slk_factor_load": (c_int, [P, c_int, P, P]),
     "slk_chol_inverse_upper": (c_int, [P, c_int, P, P, P, c_size_t, P]),

@@ -263,6 +263,21 @@ int slk_factor_load(const double *M, int n, double *A, slk_stream_t stream) {
     return SLK_OK;
 }
 
+// diag(H^-1)[j] = sum_i U[i][j]^2 for U^T U = H^-1 (one thread per column, rows in order);
+// op 0: keys = dinv (inv_diag, obq.py:73-75);  op 1: keys = -diag(Hd)[j] / dinv[j] (combined_diag, obq.py:70-72)
+__global__ __launch_bounds__(256) void k_inverse_diag_keys(const double *__restrict__ U, const float *__restrict__ H,
+                                                           const float *__restrict__ scal, int n, int op,
+                                                           double *__restrict__ keys) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double acc = 0.0;
+    for (int i = 0; i <= j; ++i) {
+        const double u = U[(size_t)i * n + j];
+        acc = fma(u, u, acc);
+    }
+    keys[j] = op == 0 ? acc : -((double)H[(size_t)j * n + j] + (double)scal[1]) / acc;
+}
+
 size_t slk_factor_payload_words(int n) { return n <= 0 ? 0 : (size_t)n * ((size_t)n + 1) / 2 + (size_t)n + 1; }
 
 int slk_factor_pack(const double *U, const long long *order, const int *info, int n, void *payload, slk_stream_t stream) {
@@ -281,6 +296,24 @@ int slk_factor_unpack(const void *payload, int n, double *U, long long *order, i
     return SLK_OK;
 }
 
+int slk_inverse_diag_keys(const double *U, const float *H, int n, float damp, int combined, double *keys,
+                          void *workspace, size_t ws_bytes, slk_stream_t stream) {
+    SLK_REQUIRE(U && H && keys && n > 0, "bad arguments");
+    Arena ws(workspace, ws_bytes);
+    float *scal = ws.take<float>(64);
+    double *tmp = ws.take<double>((size_t)n);
+    if (!scal || !tmp) {
+        set_error("workspace too small");
+        return SLK_E_WS;
+    }
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("diag_mean", 0, 4.0 * n, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
+    SLK_RUN("order_keys", 0, 12.0 * n, s, k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, nullptr, scal, tmp));
+    SLK_RUN("inverse_diag_keys", 0, 4.0 * n * n, s,
+            k_inverse_diag_keys<<<(n + 255) / 256, 256, 0, s>>>(U, H, scal, n, combined, keys));
+    return SLK_OK;
+}
+
 int slk_diag_mean(const float *H, int n, float *out, void *, size_t, slk_stream_t stream) {
     SLK_REQUIRE(H && out && n > 0, "bad arguments");
     hipStream_t s = as_stream(stream);
@@ -292,9 +325,9 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
                         long long *order_out, double *A, void *workspace, size_t ws_bytes,
                         slk_stream_t stream) {
     SLK_REQUIRE(H && order_out && A && n > 0, "bad arguments");
-    SLK_REQUIRE(order_mode >= SLK_ORDER_NONE && order_mode <= SLK_ORDER_SQERR, "Invalid act_order value %d",
+    SLK_REQUIRE(order_mode >= SLK_ORDER_NONE && order_mode <= SLK_ORDER_KEYS, "Invalid act_order value %d",
                 order_mode);
-    SLK_REQUIRE(order_mode < SLK_ORDER_ERR || miss, "err/sqerr orders need the column statistics");
+    SLK_REQUIRE(order_mode < SLK_ORDER_ERR || miss, "err/sqerr/keys orders need their input vector");
     Arena ws(workspace, ws_bytes);
     float *scal = ws.take<float>(64);
     double *keys = ws.take<double>((size_t)n);
@@ -306,8 +339,11 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
     hipStream_t s = as_stream(stream);
     const int ld = slk_factor_ld(n);
     SLK_RUN("diag_mean", 0, 4.0 * n, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
+    const bool weighted = order_mode == SLK_ORDER_ERR || order_mode == SLK_ORDER_SQERR;
     SLK_RUN("order_keys", 0, 12.0 * n, s,
-            k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, order_mode >= SLK_ORDER_ERR ? miss : nullptr, scal, keys));
+            k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, weighted ? miss : nullptr, scal, keys));
+    if (order_mode == SLK_ORDER_KEYS)  // caller-supplied float64 sort keys (ascending)
+        SLK_HIP(hipMemcpyAsync(keys, miss, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     const int identity = order_mode == SLK_ORDER_NONE;
     if (!identity) {
         SLK_HIP(hipMemsetAsync(rank, 0, sizeof(int) * (size_t)n, s));

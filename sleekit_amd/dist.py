@@ -91,7 +91,9 @@ class HipBackend:
         W, H, n = layer["W"], layer["H"], layer["H"].shape[0]
         mode = eng.order_mode_code(self.act_order)
         miss = None
-        if mode >= 2:  # err / sqerr need the statistics of ALL rows, before sharding
+        if mode == 4:  # inv_diag / combined_diag: keys from a first factorisation
+            miss = eng.inverse_diag_keys(H, n, self.damp, eng._INVERSE_ORDERS[self.act_order])
+        elif mode >= 2:  # err / sqerr need the statistics of ALL rows, before sharding
             cb = eng.require_uniform(self.quantizer)
             Ws = eng.rows_divide(W, layer["scale"]) if layer.get("scale") is not None else W
             miss = eng.column_miss(Ws, cb, mode == 3)

@@ -16,17 +16,34 @@ from . import _device as dev
 from . import _lib
 from .codebook import UniformCodebook
 
-_UNSUPPORTED_ORDERS = ("combined_diag", "inv_diag", "pivot")
+_UNSUPPORTED_ORDERS = ("pivot",)
+_INVERSE_ORDERS = {"inv_diag": 0, "combined_diag": 1}  # need diag(Hd^-1): two factorisations
 
 
 def order_mode_code(act_order):
     if act_order in _lib.ORDER_MODES:
         return _lib.ORDER_MODES[act_order]
+    if act_order in _INVERSE_ORDERS:
+        return _lib.ORDER_KEYS
     if act_order in _UNSUPPORTED_ORDERS:
         raise NotImplementedError(
-            f"act_order={act_order!r} needs a dense inverse / pivoted Cholesky and is outside the accelerated path"
+            f"act_order={act_order!r} (greedy pivoted Cholesky, obq.py:140-166) is outside the accelerated path"
         )
     raise RuntimeError(f"Invalid act_order value {act_order}")
+
+
+def inverse_diag_keys(H, n, damp, combined):
+    """Sort keys of inv_diag / combined_diag (obq.py:70-75) from a first factorisation in the original order."""
+    _, U0, info = factorize(H, n, damp, _lib.ORDER_NONE)
+    dev.note_info(info, "compute_hessian_chol")
+    ws, ws_bytes = dev.workspace(0, n)
+    keys = torch.empty(n, dtype=torch.float64, device=H.device)
+    _lib.check(
+        _lib.lib.slk_inverse_diag_keys(
+            dev.ptr(U0), dev.ptr(H), n, float(damp), int(combined), dev.ptr(keys), dev.ptr(ws), ws_bytes, dev.stream_handle()
+        )
+    )
+    return keys
 
 
 def require_uniform(quantizer):
@@ -166,11 +183,14 @@ def quantize_layer(
     R, n = W.shape
     res = LayerResult()
 
-    need_scaled_copy = scale is not None and (mode >= _lib.ORDER_ERR or nb_ls_moves > 0)
+    need_scaled_copy = scale is not None and (mode in (_lib.ORDER_ERR, _lib.ORDER_SQERR) or nb_ls_moves > 0)
     Ws, loop_scale = (rows_divide(W, scale), None) if need_scaled_copy else (W, scale)
 
     if factor is None:
-        miss = column_miss(Ws, cb_abi, mode == _lib.ORDER_SQERR) if mode >= _lib.ORDER_ERR else None
+        if mode == _lib.ORDER_KEYS:
+            miss = inverse_diag_keys(H, n, damp, _INVERSE_ORDERS[act_order])
+        else:
+            miss = column_miss(Ws, cb_abi, mode == _lib.ORDER_SQERR) if mode >= _lib.ORDER_ERR else None
         factor = factorize(H, n, damp, mode, miss)
         dev.note_info(factor[2], "compute_hessian_chol")
     res.order, res.U, res.info = factor

@@ -6,7 +6,7 @@ may be NumPy arrays (results come back as new NumPy arrays, like the reference) 
 tensors already on the GPU (results stay there; nothing synchronises).
 
 Outside the accelerated path -- present, but raising NotImplementedError: quantizers
-other than UniformCodebook, and the `combined_diag` / `inv_diag` / `pivot` orderings.
+other than UniformCodebook, and the `pivot` ordering.
 """
 
 import numpy as np
@@ -83,7 +83,9 @@ def compute_hessian_order(W, H, quantizer, act_order):
         return dev.like_input(out, W)
     Wd, Hd = dev.to_device(W), dev.to_device(H)
     miss = None
-    if mode >= _lib.ORDER_ERR:
+    if mode == _lib.ORDER_KEYS:
+        miss = engine.inverse_diag_keys(Hd, n, 0.0, engine._INVERSE_ORDERS[act_order])
+    elif mode >= _lib.ORDER_ERR:
         miss = engine.column_miss(Wd, engine.require_uniform(quantizer), mode == _lib.ORDER_SQERR)
     # damp = 0: the caller's H already carries its damping
     order, _, _ = engine.factorize_order_only(Hd, n, mode, miss)

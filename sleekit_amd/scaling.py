@@ -151,7 +151,12 @@ def compute_obq_scaling(data, codebook, axis, H, damp=0.01, act_order="diag", mi
     R, n = W.shape
     base = _no_clip_scale(W, codebook)
     mode = engine.order_mode_code(act_order)
-    miss = engine.column_miss(engine.rows_divide(W, base), cb_abi, mode == _lib.ORDER_SQERR) if mode >= _lib.ORDER_ERR else None
+    if mode == _lib.ORDER_KEYS:
+        miss = engine.inverse_diag_keys(Hd, n, damp, engine._INVERSE_ORDERS[act_order])
+    elif mode >= _lib.ORDER_ERR:
+        miss = engine.column_miss(engine.rows_divide(W, base), cb_abi, mode == _lib.ORDER_SQERR)
+    else:
+        miss = None
     order, U, info = engine.factorize(Hd, n, damp, mode, miss)
     dev.note_info(info, "compute_hessian_chol")
     factors = np.linspace(min_factor, max_factor, grid_size, dtype=np.float32)

@@ -284,6 +284,20 @@ def test_quantize_opt_direct_and_device_tensors(amd):
         amd.obq.quantize_opt(Ws, L["H"], lambda x: np.round(x))
 
 
+@pytest.mark.parametrize("order", ["inv_diag", "combined_diag"])
+def test_orders_from_the_inverse_diagonal(amd, order):
+    """obq.py:70-75: orders that need diag(Hd^-1); here from a first factorisation in the original order."""
+    for R, n, seed in ((64, 96, 2001), (96, 172, 2003)):
+        L = layer(R, n, seed)
+        g = grid.UniformGrid(8, -1, 1)
+        cb = amd.codebook.UniformCodebook(8, -1, 1)
+        want = scaling_ref.quantize_scaled(L["W"], L["scale"], g, L["H"], order, 0.01, 0)
+        got = amd.scaling.quantize_with_scaling(L["W"], L["scale"], cb, L["H"], act_order=order, damp=0.01)
+        assert np.array_equal(got, want), (order, n)
+    with pytest.raises(NotImplementedError):
+        amd.obq.quantize_opt(L["W"], L["H"], cb, act_order="pivot")
+
+
 def test_local_search_standalone(amd):
     L = layer(64, 96, 2001)
     g = grid.UniformGrid(8, -1, 1)

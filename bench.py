@@ -173,6 +173,18 @@ def main():
                 "share_of_kernel_time": round(top["total_ms"] / sum(k["total_ms"] for k in table), 3),
                 "steps_with_events_ms": round(1e3 * t_prof / args.steps, 3),
             }
+            # the other kernels of the step, same measurement (share of summed kernel time, roofline fraction)
+            def frac_of(k):
+                kd = KERNEL_DTYPE.get(k["kernel"])
+                tf = k["flops"] / PEAK[kd][0] if kd else 0.0
+                return max(tf, k["bytes"] / PEAK["hbm"][0]) / max(k["total_ms"] * 1e-3, 1e-12)
+
+            tot_ms = sum(k["total_ms"] for k in table)
+            roofline["top_kernels"] = [
+                {"kernel": k["kernel"], "share": round(k["total_ms"] / tot_ms, 3), "frac": round(frac_of(k), 4),
+                 "avg_launch_us": round(1e3 * k["total_ms"] / k["launches"], 2)}
+                for k in sorted(table, key=lambda k: -k["total_ms"])[:8]
+            ]
         if args.stages and rank == 0:
             # clean per-kernel table: one more pass on ONE stream (no kernel shares the chip)
             _lib.lib.slk_profile_enable(1)
@@ -189,6 +201,28 @@ def main():
                     f"  {k['flops'] / max(k['total_ms'], 1e-9) / 1e9:9.2f} TFLOP/s {k['bytes'] / max(k['total_ms'], 1e-9) / 1e6:9.1f} GB/s",
                     file=sys.stderr,
                 )
+
+    # ---- a1, Hessian accumulation, timed as its own stage: 2048-token batches into an n x n Hessian
+    hess = None
+    if rank == 0 and world == 1:
+        Hacc = torch.zeros((n, n), dtype=torch.float32, device=device)
+        macc = torch.zeros(n, dtype=torch.float32, device=device)
+        X = torch.randn(2048, n, device=device)
+        s_ = dev.stream_handle()
+        for it in range(2):
+            _lib.check(_lib.lib.slk_hessian_accumulate(Hacc.data_ptr(), macc.data_ptr(), X.data_ptr(), n, 2048, 2048 * it, s_))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for it in range(4):
+            _lib.check(_lib.lib.slk_hessian_accumulate(Hacc.data_ptr(), macc.data_ptr(), X.data_ptr(), n, 2048, 4096 + 2048 * it, s_))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 4
+        flops = 2048.0 * n * (n + 1)
+        hess = {"tokens_per_batch": 2048, "ms_per_batch": round(ms, 3), "achieved_tflops": round(flops / ms / 1e9, 2),
+                "peak_tflops": PEAK["mfma_f32"][0] / 1e12, "frac": round(flops / ms / 1e9 / (PEAK["mfma_f32"][0] / 1e12), 4),
+                "algorithmic_flops": "T n (n + 1): one triangle"}
 
     # ---- CPU baseline: the oracle on the host cores, one layer of the same workload
     cpu = None
@@ -222,7 +256,7 @@ def main():
                 "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(t_setup, 1),
                 "streams": {"factor": streams[0], "loop": streams[1]},
             },
-            "roofline": roofline, "cpu_baseline": cpu, "layer_error": err0,
+            "roofline": roofline, "cpu_baseline": cpu, "layer_error": err0, "hessian_accumulate": hess,
         }
         print(json.dumps(line))
     if world > 1:

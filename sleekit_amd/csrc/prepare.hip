@@ -1,120 +1,18 @@
 // Hessian preparation ahead of the factorisation (sleekit/obq.py:198-204):
 //   damping with NumPy's float32 diagonal mean, column order, and the gather of
 //   the damped, permuted, index-reversed float64 matrix the factor kernels eat.
-#include "common.h"
+#include "npsum.h"
 
 namespace slk {
 
 // ------------------------------------------------------------------ diag mean
-// NumPy float32 pairwise summation (oracle/npsum.py states the order):
-//   chunks of 8192; inside a chunk, split at (m/2 rounded down to 8) until the
-//   piece has <= 128 elements; a piece is summed with 8 interleaved accumulators.
-// One workgroup: thread 0 lists the pieces, all threads sum pieces, thread 0
-// folds the piece sums back up the same recursion.
-#define NP_CHUNK 8192
-#define NP_BLOCK 128
-#define NP_MAX_PIECES 128  // 8192 / 64
-
-__device__ float np_piece_sum(const float *a, int m) {
-    if (m < 8) {
-        float r = -0.0f;
-        for (int i = 0; i < m; ++i) r = r + a[i];
-        return r;
-    }
-    float r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
-    int i = 8;
-    for (; i < m - (m % 8); i += 8) {
-        r0 = r0 + a[i + 0];
-        r1 = r1 + a[i + 1];
-        r2 = r2 + a[i + 2];
-        r3 = r3 + a[i + 3];
-        r4 = r4 + a[i + 4];
-        r5 = r5 + a[i + 5];
-        r6 = r6 + a[i + 6];
-        r7 = r7 + a[i + 7];
-    }
-    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < m; ++i) res = res + a[i];
-    return res;
-}
-
+// mean(diag H) in float32 with NumPy's summation order (npsum.h): feeds the damping term.
 __global__ __launch_bounds__(256) void k_diag_mean(const float *__restrict__ H, int n, int ld,
                                                    float *__restrict__ out) {
-    __shared__ float vals[NP_CHUNK];
-    __shared__ int piece_lo[NP_MAX_PIECES + 1], piece_len[NP_MAX_PIECES + 1];
-    __shared__ float piece_sum[NP_MAX_PIECES + 1];
-    __shared__ int n_pieces;
-    float total = 0.0f;  // meaningful on thread 0 only
-    for (int base = 0; base < n; base += NP_CHUNK) {
-        const int m = min(NP_CHUNK, n - base);
-        for (int i = threadIdx.x; i < m; i += blockDim.x) vals[i] = H[(size_t)(base + i) * ld + (base + i)];
-        if (threadIdx.x == 0) {
-            // depth-first split, left piece first
-            int stack_lo[16], stack_len[16], sp = 0, k = 0;
-            stack_lo[0] = 0;
-            stack_len[0] = m;
-            sp = 1;
-            while (sp > 0) {
-                --sp;
-                const int lo = stack_lo[sp], len = stack_len[sp];
-                if (len <= NP_BLOCK) {
-                    piece_lo[k] = lo;
-                    piece_len[k] = len;
-                    ++k;
-                } else {
-                    int h = len / 2;
-                    h -= h % 8;
-                    stack_lo[sp] = lo + h;
-                    stack_len[sp] = len - h;
-                    ++sp;
-                    stack_lo[sp] = lo;
-                    stack_len[sp] = h;
-                    ++sp;
-                }
-            }
-            n_pieces = k;
-        }
-        __syncthreads();
-        for (int p = threadIdx.x; p < n_pieces; p += blockDim.x)
-            piece_sum[p] = np_piece_sum(vals + piece_lo[p], piece_len[p]);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // fold: post-order walk of the same recursion with an explicit frame stack
-            int f_len[16], f_stage[16], sp = 0, next = 0;
-            float f_left[16], ret = 0.0f;
-            f_len[0] = m;
-            f_stage[0] = 0;
-            sp = 1;
-            while (sp > 0) {
-                const int t = sp - 1;
-                const int len = f_len[t];
-                if (len <= NP_BLOCK) {
-                    ret = piece_sum[next++];
-                    --sp;
-                    continue;
-                }
-                int h = len / 2;
-                h -= h % 8;
-                if (f_stage[t] == 0) {
-                    f_stage[t] = 1;
-                    f_len[sp] = h;
-                    f_stage[sp] = 0;
-                    ++sp;
-                } else if (f_stage[t] == 1) {
-                    f_left[t] = ret;
-                    f_stage[t] = 2;
-                    f_len[sp] = len - h;
-                    f_stage[sp] = 0;
-                    ++sp;
-                } else {
-                    ret = f_left[t] + ret;
-                    --sp;
-                }
-            }
-            total = total + ret;
-        }
-        __syncthreads();
-    }
+    __shared__ SumTree trees[2];
+    __shared__ float terms[NP_CHUNK];
+    prepare_trees(trees, n);
+    const float total = row_sum_numpy(trees, terms, n, [&](int j) { return H[(size_t)j * ld + j]; });
     if (threadIdx.x == 0) out[0] = total / (float)n;
 }
 

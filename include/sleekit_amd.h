@@ -193,6 +193,9 @@ int slk_probe_mfma_f64_acc(double *sink, int blocks, int iters, int nacc, slk_st
  * 2: fma f32, 3: rsq f64, 4: divide f64, 5: divide f32, 6: f64->f32->f64 + mul);
  * out[0] = shader cycles, out[1] = 100 MHz ticks, out[2] = checksum.                      */
 int slk_probe_chain(double *out, int iters, int mode, slk_stream_t stream);
+/* Debug: cycle counters of workgroup 0 of the window kernel, filled when SLK_WIN_DBG has bit 3 set.
+ * host_out: 16 int64 on the HOST.  Synchronises the device.  No reference counterpart. */
+int slk_probe_window_cycles(long long *host_out, int reset);
 
 /* Per-launch timing (off by default).  While enabled, every kernel launch is bracketed by
  * HIP events on its own stream.  slk_profile_report synchronises on them and writes a JSON

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "mfma64.h"
@@ -29,6 +30,7 @@ constexpr int ULEAF = 32;     // leaves up to this width stage their U block in 
 
 struct Op {
     int kind, a, b, c;
+    int m;  // UPDATE: columns [b, m) are needed at once, [m, c) may trail behind the next leaves
 };
 struct OpTable {
     int count;
@@ -70,11 +72,12 @@ __global__ __launch_bounds__(256) void k_permute_out(const float *__restrict__ Q
 
 // ------------------------------------------------------------------ window kernel
 struct WindowSmem {
+    // leaf tables first: their offsets fit the 16-bit immediate of ds_read, so the unrolled leaf
+    // needs one address register instead of one per step
+    double u[ULEAF][ULEAF + 1];  // leaf block of U, STRICTLY upper part (zero on/below the diagonal and beyond the width)
+    double udr[ULEAF][2];        // its diagonal (1 beyond the width) and 1 / diagonal by true division
     float q[RB][WPITCH];
     float e[RB][WPITCH];
-    double u[ULEAF][ULEAF + 1];  // leaf block of U, STRICTLY upper part (zero on/below the diagonal and beyond the width)
-    double ud[ULEAF];            // its diagonal (1 beyond the width)
-    double urd[ULEAF];           // 1 / diagonal, by true division
 };
 
 // codebook.py:56-65 with the divide replaced by Markstein's sequence: with y = RN(1/step),
@@ -93,6 +96,20 @@ __device__ __forceinline__ float grid_value_fast(float x, const Grid g, float in
     return t * g.step + g.zero;
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// lane L of every 16-lane row, to all lanes of that row (DPP row_newbcast, gfx90a and later)
+template <int L>
+__device__ __forceinline__ float row_bcast(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + L, 0xf, 0xf, false));
+}
+
 // LEAF, register path (width <= 32, window in LDS), run by waves 0-3 of the workgroup: a wave
 // owns FOUR rows, 16 lanes per row; lane c keeps columns a + c and a + 16 + c of its row in two
 // registers.  Step i: column i's value is read-laned out of the four rows and selected per
@@ -102,6 +119,7 @@ __device__ __forceinline__ float grid_value_fast(float x, const Grid g, float in
 // taken once per leaf by a true division.  The loop is issue-bound (~35 instructions a step),
 // which is why four rows share a wave and the other four waves of the workgroup stay parked
 // at the barrier: two waves per SIMD would just take turns (measured 430 -> ~230 cycles/step).
+template <int NSTEP>
 __device__ __forceinline__ void leaf_registers(WindowSmem &sm, int wave, int lane, int a_rel, int w, const Grid g,
                                                float inv_step) {
     const int c16 = lane & 15, rg = lane >> 4;
@@ -109,37 +127,42 @@ __device__ __forceinline__ void leaf_registers(WindowSmem &sm, int wave, int lan
     const bool m0 = c16 < w, m1 = c16 + 16 < w;
     float x0 = m0 ? sm.q[row][a_rel + c16] : 0.0f, x1 = m1 ? sm.q[row][a_rel + 16 + c16] : 0.0f;
     float q0 = 0.0f, q1 = 0.0f, e0 = 0.0f, e1 = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        if (i < w) {  // uniform
-            const int src = i & 15;
-            const int xb = __float_as_int(i < 16 ? x0 : x1);
-            const float s0 = __int_as_float(__builtin_amdgcn_readlane(xb, src));
-            const float s1 = __int_as_float(__builtin_amdgcn_readlane(xb, 16 + src));
-            const float s2 = __int_as_float(__builtin_amdgcn_readlane(xb, 32 + src));
-            const float s3 = __int_as_float(__builtin_amdgcn_readlane(xb, 48 + src));
-            const float xi = (rg & 2) ? ((rg & 1) ? s3 : s2) : ((rg & 1) ? s1 : s0);
-            // diagonal and its reciprocal: LDS broadcast reads, off the dependency chain
-            const double uii = sm.ud[i], rii = sm.urd[i];
-            const float q = grid_value_fast(xi, g, inv_step);
-            const double d = (double)(xi - q);
-            const double qq = d * rii;
-            const double rem = __builtin_fma(-uii, qq, d);
-            const double err = __builtin_fma(rem, rii, qq);
-            const float ef = (float)err;
-            const bool here = c16 == src;
-            if (i < 16) {
-                q0 = here ? q : q0;
-                e0 = here ? ef : e0;
-            } else {
-                q1 = here ? q : q1;
-                e1 = here ? ef : e1;
-            }
-            // the staged block is zero on and below the diagonal: only later columns move
-            if (i < 15) x0 = (float)((double)x0 - err * sm.u[i][c16]);
-            x1 = (float)((double)x1 - err * sm.u[i][c16 + 16]);
+    // Steps beyond the width run on the padding (x = 0, U row = 0, diagonal = 1) and change
+    // nothing: no per-step branch, so the whole leaf is one basic block and the LDS reads of
+    // step i + 1 (U row, diagonal, reciprocal) are issued before the arithmetic of step i.
+    double u0n = sm.u[0][c16], u1n = sm.u[0][c16 + 16], uiin = sm.udr[0][0], riin = sm.udr[0][1];
+    static_for<0, NSTEP>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const double u0 = u0n, u1 = u1n, uii = uiin, rii = riin;
+        if constexpr (i + 1 < NSTEP) {
+            u0n = sm.u[i + 1][c16];
+            u1n = sm.u[i + 1][c16 + 16];
+            uiin = sm.udr[i + 1][0];
+            riin = sm.udr[i + 1][1];
         }
-    }
+        // the chain values pass through this point: the reads above are issued before step i starts
+        asm volatile("" : "+v"(x0), "+v"(x1)::"memory");
+        constexpr int src = i & 15;
+        // column i of each of the wave's four rows, broadcast inside its 16-lane DPP row
+        const float xi = row_bcast<src>(i < 16 ? x0 : x1);
+        const float q = grid_value_fast(xi, g, inv_step);
+        const double d = (double)(xi - q);
+        const double qq = d * rii;
+        const double rem = __builtin_fma(-uii, qq, d);
+        const double err = __builtin_fma(rem, rii, qq);
+        const float ef = (float)err;
+        const bool here = c16 == src;
+        if (i < 16) {
+            q0 = here ? q : q0;
+            e0 = here ? ef : e0;
+        } else {
+            q1 = here ? q : q1;
+            e1 = here ? ef : e1;
+        }
+        // the staged block is zero on and below the diagonal: only later columns move
+        if (i < 15) x0 = (float)((double)x0 - err * u0);
+        if (NSTEP > 16) x1 = (float)((double)x1 - err * u1);
+    });
     if (m0) {
         sm.q[row][a_rel + c16] = q0;
         sm.e[row][a_rel + c16] = e0;
@@ -150,9 +173,19 @@ __device__ __forceinline__ void leaf_registers(WindowSmem &sm, int wave, int lan
     }
 }
 
-// One workgroup = 512 threads = 8 waves = RB rows.  In a LEAF each wave owns two rows,
-// 32 lanes per row.  In an UPDATE the 8 waves split the target columns in 16-wide MFMA
-// blocks (M = the 16 rows of the tile), two blocks in flight per wave, K in chunks of 64.
+// One workgroup = 512 threads = 8 waves = RB rows, Q and E of the window resident in LDS.
+//
+// LEAF (fast path): waves 0-3 run the column chain, four rows each.  Waves 4-7 meanwhile run the
+// DEFERRED part of the last update on the MFMA pipe: UPDATE(a, b, c) is split at m, the end of the
+// sub-tree that follows it -- columns [b, m) are needed at once (urgent, all eight waves, the
+// chain waits for them), columns [m, c) are not touched again before the next update with the same
+// c and are folded in behind the chain's back.  Every column still sees the same updates in the
+// same order, each rounded to float32 once, so the result is the reference's bit for bit.
+// UPDATE: the target columns are cut in 16-wide MFMA blocks (M = the 16 rows of the tile), dealt
+// round-robin to the participating waves, K in chunks of 64.
+// cycle counters of workgroup 0 (SLK_WIN_DBG bit 3), read back by slk_probe_window_cycles
+__device__ long long g_win_cycles[16];
+
 template <bool IN_LDS>
 __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, float *__restrict__ Eg,
                                                      const double *__restrict__ U, int R, int n, int w0, int w1,
@@ -162,6 +195,17 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r0 = blockIdx.x * RB;
     const int width = w1 - w0;
+    const bool timing = (dbg & 8) && blockIdx.x == 0 && lane == 0;
+    long long tmark = timing ? (long long)__builtin_readcyclecounter() : 0;
+    const long long tstart = tmark;
+    // adds the cycles since the last mark to counter `slot` (wave `w` only)
+    auto lap = [&](int slot, int w) {
+        if (timing) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (wave == w) g_win_cycles[slot] += now - tmark;
+            tmark = now;
+        }
+    };
 
     // tile accessors: LDS copy of the window, or the global arrays themselves (very wide leaves).
     // Plain accesses: every producer/consumer pair below is separated by a __syncthreads().
@@ -190,6 +234,22 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
         }
     };
 
+    // Warm this XCD's L2 with the window's block of U.  All workgroups walk U in the same order at
+    // the same time, so without this every round of every update is a first touch that the whole
+    // chip waits for (measured: 2.8 us per round against 0.4 us of MFMA work).  Workgroup i runs on
+    // XCD i % 8; the workgroups of an XCD share the lines (one 4-byte touch per 128-byte line).
+    float warm = 0.0f;
+    if (IN_LDS && !(dbg & 16)) {
+        const int per_xcd = max(1, min(32, (int)gridDim.x >> 3));
+        const int slice = (blockIdx.x >> 3) % per_xcd;
+        const int lpr = (width + 15) >> 4, total = width * lpr;
+        const int per_slice = (total + per_xcd - 1) / per_xcd;
+        for (int id = slice * per_slice + t; id < min(total, (slice + 1) * per_slice); id += 512) {
+            const int row = id / lpr, c0 = (id % lpr) << 4;
+            if (c0 + 15 >= row) warm += reinterpret_cast<const float *>(U + (size_t)(w0 + row) * n + w0 + min(c0, width - 1))[0];
+        }
+    }
+
     if (IN_LDS) {
         prefetch_leaf(0);
         for (int e = t; e < RB * width; e += 512) {
@@ -198,27 +258,99 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
         }
     }
     __syncthreads();
+    lap(7, 0);
 
-    // ---- UPDATE machinery: Q[:, b:c] -= E[:, a:b] @ U[a:b, b:c] on the 16 rows of this tile.
-    // The target columns are cut in 16-wide MFMA blocks; wave v takes blocks v, v + 8, ...  A
-    // ROUND is (block, 64-deep K chunk).  Operands of U come straight from global memory (every
-    // workgroup streams the same panel out of L2), so the loads of round r+1 are issued before
-    // the MFMAs of round r, and round 0 of an update is issued BEFORE the leaf that precedes it.
+    // ---- UPDATE machinery: Q[:, lo:hi] -= E[:, a:b] @ U[a:b, lo:hi] on the 16 rows of this tile.
+    // A ROUND is (16-column block, 64-deep K chunk).  Operands of U come straight from global memory
+    // (every workgroup streams the same panel out of L2), so the loads of round r+1 are issued before
+    // the MFMAs of round r, and the chain waves issue round 0 of the urgent part BEFORE their leaf.
     const int lr = lane & 15, lk = lane >> 4;
     const bool row_ok = IN_LDS || r0 + lr < R;
     double cur[16];
-    bool have_round0 = false;
-    auto load_round = [&](const Op &u, int q, int kc, double(&bv)[16]) {
-        const int nblk = (u.c - u.b + 15) / 16;
-        const int blk = wave + 8 * q;
-        const int col = u.b + blk * 16 + lr;
-        const bool ok = blk < nblk && col < u.c;
-        const int cc = min(col, u.c - 1);
+    bool primed = false;
+    auto load_round = [&](int a, int b, int lo, int hi, int blk, int kc, double(&bv)[16]) {
+        // Clamped addresses, no masking: rows beyond b meet a zero E operand, columns beyond hi are
+        // never stored -- and any arithmetic on the loaded value here would make the wave wait for
+        // the load at once instead of after the MFMAs of the round before.
+        const int cc = min(lo + blk * 16 + lr, hi - 1);
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) {
-            const int k = u.a + 64 * kc + 4 * s4 + lk;
-            // clamp + multiply-mask: never a branch around a load
-            bv[s4] = U[(size_t)min(k, u.b - 1) * n + cc] * ((k < u.b && ok) ? 1.0 : 0.0);
+            const int k = a + 64 * kc + 4 * s4 + lk;
+            bv[s4] = U[(size_t)min(k, b - 1) * n + cc];
+        }
+    };
+    // one round of MFMAs: acc += E[:, chunk kc of a:b] @ bv.  Full and half chunks (K = 64, 32: all
+    // the reference's default schedules) take straight-line code: 16 (8) LDS reads, then the MFMAs.
+    auto mac_round = [&](int a, int b, int kc, const double(&bv)[16], double4_t &acc) {
+        const int kbase = a + 64 * kc, kcount = min(64, b - kbase);
+        if (IN_LDS && (kcount == 64 || kcount == 32)) {
+            const float *ep = &sm.e[lr][kbase - w0 + lk];
+            float av[16];
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) av[s4] = ep[4 * s4];
+            if (kcount == 64) {
+#pragma unroll
+                for (int s4 = 8; s4 < 16; ++s4) av[s4] = ep[4 * s4];
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[s4], bv[s4], acc, 0, 0, 0);
+            if (kcount == 64) {
+#pragma unroll
+                for (int s4 = 8; s4 < 16; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[s4], bv[s4], acc, 0, 0, 0);
+            }
+        } else {
+            const int er = IN_LDS ? lr : min(lr, R - 1 - r0);  // clamped: the load is unconditional, the value is selected
+#pragma unroll
+            for (int s4 = 0; s4 < 16; ++s4) {
+                const int k = kbase + 4 * s4 + lk;
+                const float ev = eld(er, min(k, b - 1));
+                const double av = (k < b && row_ok) ? (double)ev : 0.0;
+                if (4 * s4 < kcount) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[s4], acc, 0, 0, 0);
+            }
+        }
+    };
+    auto store_block = [&](int lo, int hi, int blk, const double4_t &acc) {
+        const int col = lo + blk * 16 + lr;
+        if (col < hi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = lk + 4 * r;
+                if (IN_LDS || r0 + row < R) qst(row, col, (float)((double)qld(row, col) - acc[r]));
+            }
+        }
+    };
+    // blocks wid, wid + nw, ... of [lo, hi); `ready`: cur already holds (block wid, chunk 0).
+    // Two register buffers in ping-pong, so that the loads of a round are in flight during the
+    // MFMAs of the round before and no copy ties the two together.
+    auto run_update = [&](int a, int b, int lo, int hi, int wid, int nw, bool ready) {
+        const int nblk = (hi - lo + 15) / 16, nchunk = (b - a + 63) / 64;
+        if (wid >= nblk) return;
+        const int nr = (nblk - wid + nw - 1) / nw * nchunk;
+        double other[16];
+        if (!ready) load_round(a, b, lo, hi, wid, 0, cur);
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+        int blk = wid, kc = 0;
+        for (int r = 0; r < nr; r += 2) {
+            int blk1 = blk, kc1 = kc + 1;
+            if (kc1 == nchunk) kc1 = 0, blk1 += nw;
+            const bool has1 = r + 1 < nr;
+            if (has1) load_round(a, b, lo, hi, blk1, kc1, other);
+            mac_round(a, b, kc, cur, acc);
+            if (kc + 1 == nchunk) {
+                store_block(lo, hi, blk, acc);
+                acc = zero4;
+            }
+            if (!has1) break;
+            int blk2 = blk1, kc2 = kc1 + 1;
+            if (kc2 == nchunk) kc2 = 0, blk2 += nw;
+            if (r + 2 < nr) load_round(a, b, lo, hi, blk2, kc2, cur);
+            mac_round(a, b, kc1, other, acc);
+            if (kc1 + 1 == nchunk) {
+                store_block(lo, hi, blk1, acc);
+                acc = zero4;
+            }
+            blk = blk2, kc = kc2;
         }
     };
     // generic leaf (any width, true divides): the whole workgroup in lockstep, 32 lanes per row,
@@ -233,7 +365,7 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
             if (live) {
                 x = qld(myrow, i);
                 q = grid_value(x, g);
-                const double uii = staged ? sm.ud[i - a] : U[(size_t)i * n + i];
+                const double uii = staged ? sm.udr[i - a][0] : U[(size_t)i * n + i];
                 err = (double)(x - q) / uii;
             }
             __syncthreads();  // everyone has read column i before lane 0 overwrites it
@@ -252,13 +384,17 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
         }
     };
 
+    // deferred part of the last update: Q[:, pm:pc] -= E[:, pa:pb] @ U[pa:pb, pm:pc]; pm == pc when none
+    int pa = 0, pb = 0, pm = 0, pc = 0;
+    const bool no_updates = dbg & 2, no_leaves = dbg & 1;
+
     for (int oi = 0; oi < tab.count; ++oi) {
         const Op op = tab.op[oi];
-        if ((dbg & 1) && op.kind == OP_LEAF) continue;
-        if ((dbg & 2) && op.kind != OP_LEAF) continue;
         if (op.kind == OP_LEAF) {
+            if (no_leaves) continue;
             const int a = op.a, b = op.b, w = b - a;
             const bool staged = IN_LDS && w <= ULEAF;
+            bool odd = false;  // exact-division exception: a diagonal entry whose significand is all ones
             if (staged) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -267,71 +403,63 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
                     sm.u[i][j] = (in && j > i) ? pu[h] : 0.0;
                     if (i == j) {
                         const double dg = in ? pu[h] : 1.0;
-                        sm.ud[i] = dg;
-                        sm.urd[i] = 1.0 / dg;
+                        sm.udr[i][0] = dg;
+                        sm.udr[i][1] = 1.0 / dg;
+                        odd = odd || (__double_as_longlong(dg) & 0xFFFFFFFFFFFFFLL) == 0xFFFFFFFFFFFFFLL;
                     }
                 }
             }
-            __syncthreads();
-            if (IN_LDS) prefetch_leaf(oi + 1);  // flies during this leaf and the update behind it
-            if (IN_LDS && oi + 1 < tab.count && tab.op[oi + 1].kind == OP_UPDATE && !(dbg & 2)) {
-                load_round(tab.op[oi + 1], 0, 0, cur);
-                have_round0 = true;
-            }
             bool use_fast = staged && fast_ok;
+            if (use_fast) use_fast = !__syncthreads_or(odd);
+            else __syncthreads();
+            lap(1, 0);
+            if (IN_LDS) prefetch_leaf(oi + 1);  // flies during this leaf and the update behind it
             if (use_fast) {
-                // exact-division exception: a diagonal entry whose significand is all ones
-                const int c = lane & 31;
-                const bool odd = c < w && (__double_as_longlong(sm.ud[c]) & 0xFFFFFFFFFFFFFLL) == 0xFFFFFFFFFFFFFLL;
-                use_fast = !__syncthreads_or(odd);
-            }
-            if (use_fast) {
-                // waves 0-3 take four rows each; waves 4-7 go straight to the barrier
-                if (wave < 4) leaf_registers(sm, wave, lane, a - w0, w, g, inv_step);
+                if (wave < 4) {
+                    if (oi + 1 < tab.count && tab.op[oi + 1].kind == OP_UPDATE && !no_updates) {
+                        const Op nx = tab.op[oi + 1];
+                        load_round(nx.a, nx.b, nx.b, nx.m, wave, 0, cur);
+                        primed = true;
+                    }
+                    if (!(dbg & 4)) {
+                        if (w <= 16) leaf_registers<16>(sm, wave, lane, a - w0, w, g, inv_step);
+                        else leaf_registers<32>(sm, wave, lane, a - w0, w, g, inv_step);
+                    }
+                    lap(0, 0);
+                } else if (pm < pc) {
+                    run_update(pa, pb, pm, pc, wave - 4, 4, false);
+                    lap(5, 4);
+                }
+                pm = pc;
             } else {
+                if (pm < pc) {
+                    run_update(pa, pb, pm, pc, wave, 8, false);
+                    pm = pc;
+                    __syncthreads();
+                }
                 generic_leaf(a, b, staged);
             }
             __syncthreads();
+            lap(2, 0);
+            lap(6, 4);
         } else {
-            const int a = op.a, b = op.b, c = op.c;
-            const int nblk = (c - b + 15) / 16;
-            const int nq = (nblk + 7) / 8, nchunk = (b - a + 63) / 64;
-            if (!have_round0) load_round(op, 0, 0, cur);
-            have_round0 = false;
-            for (int q = 0; q < nq; ++q) {
-                const int blk = wave + 8 * q;
-                const int col = b + blk * 16 + lr;
-                const bool ok = blk < nblk && col < c;
-                double4_t acc = {0.0, 0.0, 0.0, 0.0};
-                for (int kc = 0; kc < nchunk; ++kc) {
-                    double nxt[16];
-                    const bool last = (kc + 1 == nchunk) && (q + 1 == nq);
-                    if (!last) load_round(op, (kc + 1 == nchunk) ? q + 1 : q, (kc + 1 == nchunk) ? 0 : kc + 1, nxt);
-                    if (blk < nblk) {
-#pragma unroll
-                        for (int s4 = 0; s4 < 16; ++s4) {
-                            const int k = a + 64 * kc + 4 * s4 + lk;
-                            const double av = (k < b && row_ok) ? (double)eld(lr, min(k, b - 1)) : 0.0;
-                            if (a + 64 * kc + 4 * s4 < b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, cur[s4], acc, 0, 0, 0);
-                        }
-                    }
-                    if (!last) {
-#pragma unroll
-                        for (int s4 = 0; s4 < 16; ++s4) cur[s4] = nxt[s4];
-                    }
-                }
-                if (ok) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = lk + 4 * r;
-                        if (IN_LDS || r0 + row < R) {
-                            qst(row, col, (float)((double)qld(row, col) - acc[r]));
-                        }
-                    }
-                }
+            if (no_updates) continue;
+            if (pm < pc) {  // two updates in a row: fold the pending one in first
+                run_update(pa, pb, pm, pc, wave, 8, false);
+                pm = pc;
+                __syncthreads();
             }
+            run_update(op.a, op.b, op.b, op.m, wave, 8, primed);
+            primed = false;
+            pa = op.a, pb = op.b, pm = op.m, pc = op.c;
+            lap(3, 0);
             __syncthreads();
+            lap(4, 0);
         }
+    }
+    if (pm < pc) {
+        run_update(pa, pb, pm, pc, wave, 8, false);
+        __syncthreads();
     }
 
     if (IN_LDS) {
@@ -343,6 +471,9 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
             }
         }
     }
+    if (warm == 1.2345e-30f) g_win_cycles[15] = 1;  // keeps the touches alive
+    lap(8, 0);
+    if (timing && wave == 0) g_win_cycles[9] += (long long)__builtin_readcyclecounter() - tstart;
 }
 
 // ------------------------------------------------------------------ trailing update
@@ -390,7 +521,7 @@ __global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, c
 static void flatten(int a, int b, int mb, int nb, std::vector<Op> &ops) {
     const int size = b - a;
     if (size <= mb) {
-        ops.push_back({OP_LEAF, a, b, 0});
+        ops.push_back({OP_LEAF, a, b, 0, 0});
         return;
     }
     int step = (size + nb - 1) / nb;
@@ -398,7 +529,7 @@ static void flatten(int a, int b, int mb, int nb, std::vector<Op> &ops) {
     for (int s = a; s < b; s += step) {
         const int e = s + step < b ? s + step : b;
         flatten(s, e, mb, nb, ops);
-        if (e < b) ops.push_back({OP_UPDATE, s, e, b});
+        if (e < b) ops.push_back({OP_UPDATE, s, e, b, b});
     }
 }
 
@@ -432,6 +563,17 @@ static void plan(int a, int b, int mb, int nb, Plan &p) {
 
 using namespace slk;
 
+extern "C" int slk_probe_window_cycles(long long *host_out, int reset) {
+    SLK_REQUIRE(host_out, "null pointer");
+    SLK_HIP(hipDeviceSynchronize());
+    SLK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_win_cycles), sizeof(long long) * 16));
+    if (reset) {
+        long long zero[16] = {0};
+        SLK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_win_cycles), zero, sizeof(zero)));
+    }
+    return SLK_OK;
+}
+
 extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long long *order, const double *U,
                                  int R, int n, int levels, double lo, double hi, int min_block, int num_blocks,
                                  float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
@@ -458,6 +600,7 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
     const int fast_ok = (step_bits & 0x7FFFFFu) != 0x7FFFFFu && g.step > 9.0e-13f && g.step < 1.0e12f &&
                         getenv("SLK_NO_FAST_LEAF") == nullptr;
     const int dbg = getenv("SLK_WIN_DBG") ? atoi(getenv("SLK_WIN_DBG")) : 0;
+    const bool no_defer = getenv("SLK_NO_DEFER") != nullptr;
     static bool attr_set = false;
     if (!attr_set) {
         SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gptq_window<true>),
@@ -487,6 +630,21 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
                     } else {
                         fl += 2.0 * (q.b - q.a) * (q.c - q.b);
                         ub += 8.0 * (q.b - q.a) * (q.c - q.b);
+                    }
+                }
+                // split every update at the end of the sibling sub-tree that follows it: the columns
+                // beyond are not touched again before that sibling's own update (same c, a == this b)
+                for (int i = 0; i < tab.count; ++i) {
+                    Op &q = tab.op[i];
+                    if (q.kind != OP_UPDATE) continue;
+                    q.m = q.c;
+                    if (no_defer) continue;
+                    for (int j = i + 1; j < tab.count; ++j) {
+                        const Op &x = tab.op[j];
+                        if (x.kind == OP_UPDATE && x.c == q.c && x.a == q.b) {
+                            q.m = x.b;
+                            break;
+                        }
                     }
                 }
                 const double wbytes = 12.0 * R * (st.b - st.a) + ub;  // Q in/out + E out, U once

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Micro-benchmark (GPU box): where workgroup 0 of the window kernel spends its cycles (run with SLK_WIN_DBG=8)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from sleekit_amd import _lib, engine, codebook
+R, n = 4096, 4096
+g = torch.Generator(device="cuda").manual_seed(1)
+W = torch.randn(R, n, device="cuda", generator=g) * 0.5
+U = torch.triu(torch.randn(n, n, device="cuda", dtype=torch.float64, generator=g) * 0.01) + torch.eye(n, device="cuda", dtype=torch.float64)
+order = torch.arange(n, device="cuda")
+cb = codebook.UniformCodebook(8, -1, 1)._abi()
+buf = (ctypes.c_longlong * 16)()
+engine.run_loop(W, None, order, U, cb, 32, 8)
+_lib.check(_lib.lib.slk_probe_window_cycles(buf, 1))
+reps = 3
+for rep in range(reps):
+    engine.run_loop(W, None, order, U, cb, 32, 8)
+_lib.check(_lib.lib.slk_probe_window_cycles(buf, 1))
+names = {0: "leaf chain (wave 0)", 1: "stage + barrier before leaf", 2: "barrier after leaf (wave 0)", 3: "urgent update (wave 0)",
+         4: "barrier after update", 5: "deferred update (wave 4)", 6: "wave 4: barrier after its part", 7: "tile load", 8: "tile store", 9: "kernel total"}
+launches = reps * 8
+for k, name in names.items():
+    print(f"  {name:<32s} {buf[k] / launches / 2400.0:8.2f} us per window launch")

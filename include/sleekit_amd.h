@@ -196,6 +196,9 @@ int slk_probe_chain(double *out, int iters, int mode, slk_stream_t stream);
 /* Debug: cycle counters of workgroup 0 of the window kernel, filled when SLK_WIN_DBG has bit 3 set.
  * host_out: 16 int64 on the HOST.  Synchronises the device.  No reference counterpart. */
 int slk_probe_window_cycles(long long *host_out, int reset);
+/* Debug: the leaf chain alone (32-column leaves, 8-level grid) on one workgroup with one or two waves per
+ * SIMD.  out (DEVICE, 2 doubles): cycles wave 0 spent on `iters` leaves, checksum. */
+int slk_probe_leaf_chain(double *out, int iters, int waves_per_simd, slk_stream_t stream);
 
 /* Per-launch timing (off by default).  While enabled, every kernel launch is bracketed by
  * HIP events on its own stream.  slk_profile_report synchronises on them and writes a JSON

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "slk_probe_mfma_f64_acc": (c_int, [P, c_int, c_int, c_int, P]),
     "slk_probe_chain": (c_int, [P, c_int, c_int, P]),
     "slk_probe_window_cycles": (c_int, [P, c_int]),
+    "slk_probe_leaf_chain": (c_int, [P, c_int, c_int, P]),
     "slk_profile_enable": (c_int, [c_int]),
     "slk_profile_reset": (c_int, []),
     "slk_profile_report": (c_int, [c_char_p, c_size_t]),

@@ -131,9 +131,15 @@ int slk_probe_mfma_f64(double *sink, int blocks, int iters, slk_stream_t stream)
 }
 
 int slk_probe_mfma_f64_acc(double *sink, int blocks, int iters, int nacc, slk_stream_t stream) {
-    SLK_REQUIRE(sink && blocks > 0 && iters > 0 && (nacc == 8 || nacc == 16), "bad arguments");
+    SLK_REQUIRE(sink && blocks > 0 && iters > 0 && (nacc == 1 || nacc == 2 || nacc == 4 || nacc == 8 || nacc == 16), "bad arguments");
     hipStream_t s = as_stream(stream);
-    if (nacc == 8)
+    if (nacc == 1)
+        SLK_RUN("probe_mfma_f64", 1.0 * 2048 * 4 * iters * blocks, 0, s, k_probe_f64_n<1><<<blocks, 256, 0, s>>>(sink, iters));
+    else if (nacc == 2)
+        SLK_RUN("probe_mfma_f64", 2.0 * 2048 * 4 * iters * blocks, 0, s, k_probe_f64_n<2><<<blocks, 256, 0, s>>>(sink, iters));
+    else if (nacc == 4)
+        SLK_RUN("probe_mfma_f64", 4.0 * 2048 * 4 * iters * blocks, 0, s, k_probe_f64_n<4><<<blocks, 256, 0, s>>>(sink, iters));
+    else if (nacc == 8)
         SLK_RUN("probe_mfma_f64", 8.0 * 2048 * 4 * iters * blocks, 0, s, k_probe_f64_n<8><<<blocks, 256, 0, s>>>(sink, iters));
     else
         SLK_RUN("probe_mfma_f64", 16.0 * 2048 * 4 * iters * blocks, 0, s, k_probe_f64_n<16><<<blocks, 256, 0, s>>>(sink, iters));

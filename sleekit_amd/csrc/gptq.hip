@@ -30,7 +30,8 @@ constexpr int ULEAF = 32;     // leaves up to this width stage their U block in 
 
 struct Op {
     int kind, a, b, c;
-    int m;  // UPDATE: columns [b, m) are needed at once, [m, c) may trail behind the next leaves
+    int m;   // UPDATE: columns [b, m) are needed at once, [m, c) may trail behind the next leaves
+    int nl;  // UPDATE: number of leaves before [m, c) is touched again
 };
 struct OpTable {
     int count;
@@ -71,11 +72,16 @@ __global__ __launch_bounds__(256) void k_permute_out(const float *__restrict__ Q
 }
 
 // ------------------------------------------------------------------ window kernel
-struct WindowSmem {
-    // leaf tables first: their offsets fit the 16-bit immediate of ds_read, so the unrolled leaf
-    // needs one address register instead of one per step
+struct LeafTables {
     double u[ULEAF][ULEAF + 1];  // leaf block of U, STRICTLY upper part (zero on/below the diagonal and beyond the width)
     double udr[ULEAF][2];        // its diagonal (1 beyond the width) and 1 / diagonal by true division
+};
+struct WindowSmem {
+    // leaf tables first: their offsets fit the 16-bit immediate of ds_read, so the unrolled leaf
+    // needs one address register instead of one per step.  Two copies: the helper waves fill the
+    // tables of the next leaf while the chain waves read those of the current one.
+    LeafTables lt[2];
+    int odd[2][4];  // per helper wave: a diagonal entry of that block defeats the exact-division shortcut
     float q[RB][WPITCH];
     float e[RB][WPITCH];
 };
@@ -120,8 +126,8 @@ __device__ __forceinline__ float row_bcast(float x) {
 // which is why four rows share a wave and the other four waves of the workgroup stay parked
 // at the barrier: two waves per SIMD would just take turns (measured 430 -> ~230 cycles/step).
 template <int NSTEP>
-__device__ __forceinline__ void leaf_registers(WindowSmem &sm, int wave, int lane, int a_rel, int w, const Grid g,
-                                               float inv_step) {
+__device__ __forceinline__ void leaf_registers(WindowSmem &sm, const LeafTables &lt, int wave, int lane, int a_rel, int w,
+                                               const Grid g, float inv_step) {
     const int c16 = lane & 15, rg = lane >> 4;
     const int row = 4 * wave + rg;
     const bool m0 = c16 < w, m1 = c16 + 16 < w;
@@ -130,15 +136,15 @@ __device__ __forceinline__ void leaf_registers(WindowSmem &sm, int wave, int lan
     // Steps beyond the width run on the padding (x = 0, U row = 0, diagonal = 1) and change
     // nothing: no per-step branch, so the whole leaf is one basic block and the LDS reads of
     // step i + 1 (U row, diagonal, reciprocal) are issued before the arithmetic of step i.
-    double u0n = sm.u[0][c16], u1n = sm.u[0][c16 + 16], uiin = sm.udr[0][0], riin = sm.udr[0][1];
+    double u0n = lt.u[0][c16], u1n = lt.u[0][c16 + 16], uiin = lt.udr[0][0], riin = lt.udr[0][1];
     static_for<0, NSTEP>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const double u0 = u0n, u1 = u1n, uii = uiin, rii = riin;
         if constexpr (i + 1 < NSTEP) {
-            u0n = sm.u[i + 1][c16];
-            u1n = sm.u[i + 1][c16 + 16];
-            uiin = sm.udr[i + 1][0];
-            riin = sm.udr[i + 1][1];
+            u0n = lt.u[i + 1][c16];
+            u1n = lt.u[i + 1][c16 + 16];
+            uiin = lt.udr[i + 1][0];
+            riin = lt.udr[i + 1][1];
         }
         // the chain values pass through this point: the reads above are issued before step i starts
         asm volatile("" : "+v"(x0), "+v"(x1)::"memory");
@@ -173,19 +179,21 @@ __device__ __forceinline__ void leaf_registers(WindowSmem &sm, int wave, int lan
     }
 }
 
-// One workgroup = 512 threads = 8 waves = RB rows, Q and E of the window resident in LDS.
-//
-// LEAF (fast path): waves 0-3 run the column chain, four rows each.  Waves 4-7 meanwhile run the
-// DEFERRED part of the last update on the MFMA pipe: UPDATE(a, b, c) is split at m, the end of the
-// sub-tree that follows it -- columns [b, m) are needed at once (urgent, all eight waves, the
-// chain waits for them), columns [m, c) are not touched again before the next update with the same
-// c and are folded in behind the chain's back.  Every column still sees the same updates in the
-// same order, each rounded to float32 once, so the result is the reference's bit for bit.
-// UPDATE: the target columns are cut in 16-wide MFMA blocks (M = the 16 rows of the tile), dealt
-// round-robin to the participating waves, K in chunks of 64.
 // cycle counters of workgroup 0 (SLK_WIN_DBG bit 3), read back by slk_probe_window_cycles
 __device__ long long g_win_cycles[16];
 
+// One workgroup = 512 threads = 8 waves = RB rows, Q and E of the window resident in LDS.
+//
+// LEAF (fast path): waves 0-3, the CHAIN waves, run the column chain, four rows each.  Waves 4-7,
+// the HELPERS, meanwhile (a) write the U tables of the next leaf into the other LDS buffer and
+// fetch those of the one after, (b) run a share of the DEFERRED part of the last update on the MFMA
+// pipe: UPDATE(a, b, c) is split at m, the end of the sub-tree that follows it -- columns [b, m) are
+// needed at once (urgent, all eight waves, the chain waits for them), columns [m, c) are not touched
+// again before the next update with the same c and are folded in behind the chain's back, spread
+// over the `nl` leaves in between.  Every column still sees the same updates in the same order,
+// each rounded to float32 once, so the result is the reference's bit for bit.
+// UPDATE: the target columns are cut in 16-wide MFMA blocks (M = the 16 rows of the tile), dealt
+// round-robin to the participating waves, K in chunks of 64.
 template <bool IN_LDS>
 __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, float *__restrict__ Eg,
                                                      const double *__restrict__ U, int R, int n, int w0, int w1,
@@ -193,16 +201,20 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     WindowSmem &sm = *reinterpret_cast<WindowSmem *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool helper = wave >= 4;
+    const int ht = t - 256;  // helper thread index
     const int r0 = blockIdx.x * RB;
     const int width = w1 - w0;
-    const bool timing = (dbg & 8) && blockIdx.x == 0 && lane == 0;
+    // cycle accounting (debug): wave-uniform accumulators, written out once at the end
+    const bool timing = (dbg & 8) && blockIdx.x == 0;
     long long tmark = timing ? (long long)__builtin_readcyclecounter() : 0;
     const long long tstart = tmark;
+    long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // adds the cycles since the last mark to counter `slot` (wave `w` only)
     auto lap = [&](int slot, int w) {
         if (timing) {
             const long long now = (long long)__builtin_readcyclecounter();
-            if (wave == w) g_win_cycles[slot] += now - tmark;
+            if (wave == w) tacc[slot] += now - tmark;
             tmark = now;
         }
     };
@@ -217,27 +229,58 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
     auto est = [&](int r, int c, float v) {
         if (IN_LDS) sm.e[r][c - w0] = v; else Eg[(size_t)(r0 + r) * n + c] = v;
     };
-    // Register prefetch of the next staged leaf's U block (<= 32 x 32 doubles over 512 threads).
-    double pu[2] = {0.0, 0.0};
-    auto prefetch_leaf = [&](int from) {
-        for (int oj = from; oj < tab.count; ++oj) {
-            const Op nx = tab.op[oj];
-            if (nx.kind != OP_LEAF) continue;
-            const int w = nx.b - nx.a;
-            if (w > ULEAF) return;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int e = t + 512 * h, i = e >> 5, j = e & 31;
-                if (i < w && j < w && j >= i) pu[h] = U[(size_t)(nx.a + i) * n + nx.a + j];
-            }
-            return;
+    // columns [c_lo, c_hi) of the Q tile, global -> LDS, by `nth` threads of which this is number `tid`
+    auto load_cols = [&](int c_lo, int c_hi, int tid, int nth) {
+        const int cw = c_hi - c_lo;
+        for (int e = tid; e < RB * cw; e += nth) {
+            const int r = e / cw, c = c_lo + e % cw;
+            sm.q[r][c - w0] = (r0 + r < R) ? Qp[(size_t)(r0 + r) * n + c] : 0.0f;
         }
     };
 
-    // Warm this XCD's L2 with the window's block of U.  All workgroups walk U in the same order at
-    // the same time, so without this every round of every update is a first touch that the whole
-    // chip waits for (measured: 2.8 us per round against 0.4 us of MFMA work).  Workgroup i runs on
-    // XCD i % 8; the workgroups of an XCD share the lines (one 4-byte touch per 128-byte line).
+    // ---- staging pipeline of the leaf tables (helpers only): registers <- U two staged leaves
+    // ahead, LDS buffer <- registers one leaf ahead.
+    double pu[4] = {0.0, 0.0, 0.0, 0.0};
+    int fetch_w = 0;     // width of the block held in pu, 0 = none
+    int next_fetch = 0;  // op from which to look for the next staged leaf
+    auto fetch_block = [&]() {
+        fetch_w = 0;
+        for (; next_fetch < tab.count; ++next_fetch) {
+            const Op nx = tab.op[next_fetch];
+            const int w = nx.b - nx.a;
+            if (nx.kind != OP_LEAF || w > ULEAF) continue;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int e = ht + 256 * h, i = min(e >> 5, w - 1), j = min(e & 31, w - 1);
+                pu[h] = U[(size_t)(nx.a + i) * n + nx.a + j];  // clamped, selected when written
+            }
+            fetch_w = w;
+            ++next_fetch;
+            return;
+        }
+    };
+    auto write_block = [&](int buf) {
+        LeafTables &lt = sm.lt[buf];
+        const int w = fetch_w;
+        bool odd = false;  // exact-division exception: a diagonal entry whose significand is all ones
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int e = ht + 256 * h, i = e >> 5, j = e & 31;  // all 32 x 32 slots
+            const bool in = i < w && j < w;
+            lt.u[i][j] = (in && j > i) ? pu[h] : 0.0;
+            if (i == j) {
+                const double dg = in ? pu[h] : 1.0;
+                lt.udr[i][0] = dg;
+                lt.udr[i][1] = 1.0 / dg;
+                odd = odd || (__double_as_longlong(dg) & 0xFFFFFFFFFFFFFLL) == 0xFFFFFFFFFFFFFLL;
+            }
+        }
+        const bool any = __builtin_amdgcn_ballot_w64(odd) != 0;
+        if (lane == 0) sm.odd[buf][wave - 4] = any ? 1 : 0;
+    };
+
+    // Warm this XCD's L2 with the window's block of U (workgroup i runs on XCD i % 8; the
+    // workgroups of an XCD share the lines, one 4-byte touch per 128-byte line).
     float warm = 0.0f;
     if (IN_LDS && !(dbg & 16)) {
         const int per_xcd = max(1, min(32, (int)gridDim.x >> 3));
@@ -250,11 +293,17 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
         }
     }
 
+    // Prologue: only the first leaf's columns are needed before the first barrier; the rest of the
+    // tile is loaded by the helpers during that leaf.
+    int rest_from = w1;  // columns [rest_from, w1) of the tile still to be loaded
     if (IN_LDS) {
-        prefetch_leaf(0);
-        for (int e = t; e < RB * width; e += 512) {
-            const int r = e / width, c = e % width;
-            sm.q[r][c] = (r0 + r < R) ? Qp[(size_t)(r0 + r) * n + w0 + c] : 0.0f;
+        if (helper) fetch_block();
+        const int first_end = (tab.op[0].kind == OP_LEAF && !(dbg & 32)) ? tab.op[0].b : w1;
+        load_cols(w0, first_end, t, 512);
+        rest_from = first_end;
+        if (helper) {
+            if (fetch_w) write_block(0);
+            fetch_block();
         }
     }
     __syncthreads();
@@ -273,6 +322,12 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
         // never stored -- and any arithmetic on the loaded value here would make the wave wait for
         // the load at once instead of after the MFMAs of the round before.
         const int cc = min(lo + blk * 16 + lr, hi - 1);
+        if (dbg & 64) {  // EXPERIMENT: contiguous 8 KB per round (wrong values)
+            const double *pk = U + (size_t)a * n + (size_t)((lo - b) / 16 + blk) * 1024 + lk * 16 + lr;
+#pragma unroll
+            for (int s4 = 0; s4 < 16; ++s4) bv[s4] = pk[s4 * 64];
+            return;
+        }
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) {
             const int k = a + 64 * kc + 4 * s4 + lk;
@@ -356,7 +411,8 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
     // generic leaf (any width, true divides): the whole workgroup in lockstep, 32 lanes per row,
     // one barrier per column.  Rare (width > 32, or a diagonal hitting the exact-division
     // exception), so simplicity wins.
-    auto generic_leaf = [&](int a, int b, bool staged) {
+    auto generic_leaf = [&](int a, int b, bool staged, int buf) {
+        const LeafTables &lt = sm.lt[buf];
         const int myrow = 2 * wave + (lane >> 5), l = lane & 31;
         const bool live = IN_LDS || (r0 + myrow < R);
         for (int i = a; i < b; ++i) {
@@ -365,13 +421,13 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
             if (live) {
                 x = qld(myrow, i);
                 q = grid_value(x, g);
-                const double uii = staged ? sm.udr[i - a][0] : U[(size_t)i * n + i];
+                const double uii = staged ? lt.udr[i - a][0] : U[(size_t)i * n + i];
                 err = (double)(x - q) / uii;
             }
             __syncthreads();  // everyone has read column i before lane 0 overwrites it
             if (live) {
                 for (int j = i + 1 + l; j < b; j += 32) {
-                    const double uij = staged ? sm.u[i - a][j - a] : U[(size_t)i * n + j];
+                    const double uij = staged ? lt.u[i - a][j - a] : U[(size_t)i * n + j];
                     const double p = err * uij;
                     qst(myrow, j, (float)((double)qld(myrow, j) - p));
                 }
@@ -384,82 +440,103 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
         }
     };
 
-    // deferred part of the last update: Q[:, pm:pc] -= E[:, pa:pb] @ U[pa:pb, pm:pc]; pm == pc when none
-    int pa = 0, pb = 0, pm = 0, pc = 0;
+    // deferred part of the last update: Q[:, pm:pc] -= E[:, pa:pb] @ U[pa:pb, pm:pc], of which the
+    // first pdone 16-column blocks are done and the rest is due within pleaves more leaves
+    int pa = 0, pb = 0, pm = 0, pc = 0, pdone = 0, pleaves = 1;
     const bool no_updates = dbg & 2, no_leaves = dbg & 1;
+    int sbuf = 0;  // LDS buffer holding the tables of the next staged leaf
 
-    for (int oi = 0; oi < tab.count; ++oi) {
-        const Op op = tab.op[oi];
-        if (op.kind == OP_LEAF) {
-            if (no_leaves) continue;
-            const int a = op.a, b = op.b, w = b - a;
-            const bool staged = IN_LDS && w <= ULEAF;
-            bool odd = false;  // exact-division exception: a diagonal entry whose significand is all ones
-            if (staged) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int e = t + 512 * h, i = e >> 5, j = e & 31;  // all 32 x 32 slots
-                    const bool in = i < w && j < w;
-                    sm.u[i][j] = (in && j > i) ? pu[h] : 0.0;
-                    if (i == j) {
-                        const double dg = in ? pu[h] : 1.0;
-                        sm.udr[i][0] = dg;
-                        sm.udr[i][1] = 1.0 / dg;
-                        odd = odd || (__double_as_longlong(dg) & 0xFFFFFFFFFFFFFLL) == 0xFFFFFFFFFFFFFLL;
-                    }
-                }
-            }
-            bool use_fast = staged && fast_ok;
-            if (use_fast) use_fast = !__syncthreads_or(odd);
-            else __syncthreads();
+    // One pass per op plus a final pass that folds in whatever is still pending.  Each pass: at most
+    // one update job per wave (ONE call site of run_update: it is big), then the leaf, then a barrier.
+    for (int oi = 0; oi <= tab.count; ++oi) {
+        const bool fin = oi == tab.count;
+        const Op op = tab.op[fin ? 0 : oi];
+        const bool is_leaf = !fin && op.kind == OP_LEAF;
+        if (!fin && (is_leaf ? no_leaves : no_updates)) continue;
+        const int prem = (pc - pm + 15) / 16 - pdone;  // pending blocks
+        const int plo = pm + 16 * pdone;
+        // the update job of this wave in this pass: Q[:, ulo:uhi] -= E[:, ua:ub] @ U[ua:ub, ulo:uhi]
+        int ua = 0, ub = 0, ulo = 0, uhi = 0, uwid = wave, unw = 8;
+        bool uready = false, redo = false, use_fast = false, staged = false;
+        if (is_leaf) {
+            const int w = op.b - op.a;
+            staged = IN_LDS && w <= ULEAF;
+            use_fast = staged && fast_ok;
+            if (use_fast) use_fast = (sm.odd[sbuf][0] | sm.odd[sbuf][1] | sm.odd[sbuf][2] | sm.odd[sbuf][3]) == 0;
             lap(1, 0);
-            if (IN_LDS) prefetch_leaf(oi + 1);  // flies during this leaf and the update behind it
             if (use_fast) {
-                if (wave < 4) {
-                    if (oi + 1 < tab.count && tab.op[oi + 1].kind == OP_UPDATE && !no_updates) {
-                        const Op nx = tab.op[oi + 1];
-                        load_round(nx.a, nx.b, nx.b, nx.m, wave, 0, cur);
-                        primed = true;
-                    }
-                    if (!(dbg & 4)) {
-                        if (w <= 16) leaf_registers<16>(sm, wave, lane, a - w0, w, g, inv_step);
-                        else leaf_registers<32>(sm, wave, lane, a - w0, w, g, inv_step);
-                    }
-                    lap(0, 0);
-                } else if (pm < pc) {
-                    run_update(pa, pb, pm, pc, wave - 4, 4, false);
-                    lap(5, 4);
+                // this leaf's share of the pending blocks, in whole turns of the four helpers
+                const int take = prem > 0 ? min(prem, ((prem + pleaves - 1) / pleaves + 3) & ~3) : 0;
+                if (helper) {
+                    if (rest_from < w1) load_cols(rest_from, w1, ht, 256);
+                    if (fetch_w) write_block(sbuf ^ 1);
+                    fetch_block();
+                    ua = pa, ub = pb, ulo = plo, uhi = min(pc, plo + 16 * take), uwid = wave - 4, unw = 4;
+                } else if (oi + 1 < tab.count && tab.op[oi + 1].kind == OP_UPDATE && !no_updates) {
+                    const Op nx = tab.op[oi + 1];
+                    load_round(nx.a, nx.b, nx.b, nx.m, wave, 0, cur);
+                    primed = true;
                 }
-                pm = pc;
+                pdone += take;
+                pleaves = max(1, pleaves - 1);
             } else {
-                if (pm < pc) {
-                    run_update(pa, pb, pm, pc, wave, 8, false);
-                    pm = pc;
-                    __syncthreads();
+                if (rest_from < w1) load_cols(rest_from, w1, t, 512);
+                if (helper && staged) {
+                    if (fetch_w) write_block(sbuf ^ 1);
+                    fetch_block();
                 }
-                generic_leaf(a, b, staged);
+                ua = pa, ub = pb, ulo = plo, uhi = pc;  // everything pending, all eight waves
+                pdone += prem;
             }
-            __syncthreads();
+            rest_from = w1;
+        } else if (fin) {
+            const bool rest = rest_from < w1;  // no leaf ran (debug modes)
+            if (rest) load_cols(rest_from, w1, t, 512);
+            rest_from = w1;
+            if (prem <= 0 && !rest) break;
+            ua = pa, ub = pb, ulo = plo, uhi = pc;
+            pdone += prem;
+        } else if (prem > 0 && ((op.c > plo && op.b < pc) || op.m < op.c)) {
+            // an update that meets columns still pending, or has a deferred part of its own while the
+            // older one is unfinished (never under the host's leaf counts, unless leaves were
+            // skipped): fold the pending columns in first, then come back
+            ua = pa, ub = pb, ulo = plo, uhi = pc;
+            pdone += prem;
+            redo = true;
+        } else {
+            ua = op.a, ub = op.b, ulo = op.b, uhi = op.m, uready = primed;
+            primed = false;
+            // an update without a deferred part (a small one between two leaves) leaves the older
+            // deferral alone: that one keeps trailing behind the following leaves
+            if (op.m < op.c) pa = op.a, pb = op.b, pm = op.m, pc = op.c, pdone = 0, pleaves = max(1, op.nl);
+        }
+        if (!is_leaf) lap(10, 0);
+        if (ulo < uhi) run_update(ua, ub, ulo, uhi, uwid, unw, uready);
+        if (is_leaf) {
+            if (use_fast) {
+                if (!helper && !(dbg & 4)) {
+                    const int w = op.b - op.a;
+                    if (w <= 16) leaf_registers<16>(sm, sm.lt[sbuf], wave, lane, op.a - w0, w, g, inv_step);
+                    else leaf_registers<32>(sm, sm.lt[sbuf], wave, lane, op.a - w0, w, g, inv_step);
+                }
+                lap(0, 0);
+                lap(5, 4);
+            } else {
+                __syncthreads();
+                generic_leaf(op.a, op.b, staged, sbuf);
+            }
+            if (staged) sbuf ^= 1;
+        } else {
+            lap(3, 0);
+        }
+        __syncthreads();
+        if (is_leaf) {
             lap(2, 0);
             lap(6, 4);
         } else {
-            if (no_updates) continue;
-            if (pm < pc) {  // two updates in a row: fold the pending one in first
-                run_update(pa, pb, pm, pc, wave, 8, false);
-                pm = pc;
-                __syncthreads();
-            }
-            run_update(op.a, op.b, op.b, op.m, wave, 8, primed);
-            primed = false;
-            pa = op.a, pb = op.b, pm = op.m, pc = op.c;
-            lap(3, 0);
-            __syncthreads();
             lap(4, 0);
         }
-    }
-    if (pm < pc) {
-        run_update(pa, pb, pm, pc, wave, 8, false);
-        __syncthreads();
+        if (redo) --oi;
     }
 
     if (IN_LDS) {
@@ -473,7 +550,14 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
     }
     if (warm == 1.2345e-30f) g_win_cycles[15] = 1;  // keeps the touches alive
     lap(8, 0);
-    if (timing && wave == 0) g_win_cycles[9] += (long long)__builtin_readcyclecounter() - tstart;
+    if (timing && lane == 0) {
+        if (wave == 0) tacc[9] += (long long)__builtin_readcyclecounter() - tstart;
+        if (wave == 0 || wave == 4) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                if (tacc[k]) g_win_cycles[k] += tacc[k];
+        }
+    }
 }
 
 // ------------------------------------------------------------------ trailing update
@@ -521,7 +605,7 @@ __global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, c
 static void flatten(int a, int b, int mb, int nb, std::vector<Op> &ops) {
     const int size = b - a;
     if (size <= mb) {
-        ops.push_back({OP_LEAF, a, b, 0, 0});
+        ops.push_back({OP_LEAF, a, b, 0, 0, 0});
         return;
     }
     int step = (size + nb - 1) / nb;
@@ -529,7 +613,7 @@ static void flatten(int a, int b, int mb, int nb, std::vector<Op> &ops) {
     for (int s = a; s < b; s += step) {
         const int e = s + step < b ? s + step : b;
         flatten(s, e, mb, nb, ops);
-        if (e < b) ops.push_back({OP_UPDATE, s, e, b, b});
+        if (e < b) ops.push_back({OP_UPDATE, s, e, b, b, 1});
     }
 }
 
@@ -562,6 +646,41 @@ static void plan(int a, int b, int mb, int nb, Plan &p) {
 }  // namespace slk
 
 using namespace slk;
+
+namespace slk {
+// the leaf chain alone: `iters` leaves of 32 columns on the tables of a made-up block; out[0] = cycles
+// of wave 0, out[1] = checksum.  blockDim = 256 (one wave per SIMD) or 512 (two).
+__global__ void k_probe_leaf(double *out, int iters, Grid g, float inv_step) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    WindowSmem &sm = *reinterpret_cast<WindowSmem *>(smem_raw);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int e = t; e < 32 * 32; e += blockDim.x) {
+        const int i = e >> 5, j = e & 31;
+        sm.lt[0].u[i][j] = j > i ? 0.01 * ((i * 7 + j * 3) % 11 - 5) : 0.0;
+        if (i == j) sm.lt[0].udr[i][0] = 1.0 + 0.01 * i, sm.lt[0].udr[i][1] = 1.0 / (1.0 + 0.01 * i);
+    }
+    for (int e = t; e < RB * 64; e += blockDim.x) sm.q[e >> 6][e & 63] = 0.37f * ((e * 13) % 17 - 8);
+    __syncthreads();
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) leaf_registers<32>(sm, sm.lt[0], wave & 3, lane, (it & 1) * 32, 32, g, inv_step);
+    const long long t1 = (long long)__builtin_readcyclecounter();
+    __syncthreads();
+    if (t == 0) {
+        out[0] = (double)(t1 - t0);
+        out[1] = sm.q[3][5] + sm.e[2][7];
+    }
+}
+}  // namespace slk
+
+extern "C" int slk_probe_leaf_chain(double *out, int iters, int waves_per_simd, slk_stream_t stream) {
+    SLK_REQUIRE(out && iters > 0 && (waves_per_simd == 1 || waves_per_simd == 2), "bad arguments");
+    hipStream_t s = as_stream(stream);
+    const Grid g = make_grid(8, -1.0, 1.0);
+    SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_probe_leaf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sizeof(WindowSmem)));
+    SLK_RUN("probe_leaf", 0, 0, s, k_probe_leaf<<<1, 256 * waves_per_simd, sizeof(WindowSmem), s>>>(out, iters, g, 1.0f / g.step));
+    return SLK_OK;
+}
 
 extern "C" int slk_probe_window_cycles(long long *host_out, int reset) {
     SLK_REQUIRE(host_out, "null pointer");
@@ -638,11 +757,15 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
                     Op &q = tab.op[i];
                     if (q.kind != OP_UPDATE) continue;
                     q.m = q.c;
+                    q.nl = 1;
                     if (no_defer) continue;
+                    int leaves = 0;
                     for (int j = i + 1; j < tab.count; ++j) {
                         const Op &x = tab.op[j];
+                        if (x.kind == OP_LEAF) ++leaves;
                         if (x.kind == OP_UPDATE && x.c == q.c && x.a == q.b) {
                             q.m = x.b;
+                            q.nl = leaves > 0 ? leaves : 1;
                             break;
                         }
                     }

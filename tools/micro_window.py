@@ -19,7 +19,7 @@ for rep in range(reps):
     engine.run_loop(W, None, order, U, cb, 32, 8)
 _lib.check(_lib.lib.slk_probe_window_cycles(buf, 1))
 names = {0: "leaf chain (wave 0)", 1: "stage + barrier before leaf", 2: "barrier after leaf (wave 0)", 3: "urgent update (wave 0)",
-         4: "barrier after update", 5: "deferred update (wave 4)", 6: "wave 4: barrier after its part", 7: "tile load", 8: "tile store", 9: "kernel total"}
+         4: "barrier after update", 5: "deferred update (wave 4)", 6: "wave 4: barrier after its part", 7: "tile load", 8: "tile store", 9: "kernel total", 10: "update pass set-up (wave 0)", 11: "aux 11", 12: "aux 12"}
 launches = reps * 8
 for k, name in names.items():
     print(f"  {name:<32s} {buf[k] / launches / 2400.0:8.2f} us per window launch")

@@ -560,6 +560,10 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
     }
 }
 
+}  // namespace slk
+#include "window2.h"
+namespace slk {
+
 // ------------------------------------------------------------------ trailing update
 // Qp[:, ja:jb] = float32(float64(Qp[:, ja:jb]) - E[:, ka:kb] @ U[ka:kb, ja:jb]), 64 x 64 tiles.
 __global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, const float *__restrict__ Eg,
@@ -643,6 +647,37 @@ static void plan(int a, int b, int mb, int nb, Plan &p) {
     }
 }
 
+// A window's ops as periods (window2.h), or false when the window is not of the standard shape.
+static bool as_periods(const std::vector<Op> &ops, int wa, int wb, PeriodTable &pt) {
+    pt.count = 0;
+    size_t i = 0;
+    while (i < ops.size()) {
+        if (pt.count == MAXP || ops[i].kind != OP_LEAF) return false;
+        Period P = {ops[i].a, ops[i].b - ops[i].a, 0, 0};
+        ++i;
+        if (i + 1 < ops.size() && ops[i].kind == OP_UPDATE && ops[i].a == P.s && ops[i].b == P.s + P.w1 &&
+            ops[i + 1].kind == OP_LEAF && ops[i + 1].a == P.s + P.w1 && ops[i].c == ops[i + 1].b) {
+            P.w2 = ops[i + 1].b - ops[i + 1].a;
+            i += 2;
+        }
+        const int K = P.w1 + P.w2;
+        if (i < ops.size()) {
+            if (ops[i].kind != OP_UPDATE || ops[i].a != P.s || ops[i].b != P.s + K || ops[i].c != wb) return false;
+            ++i;
+        } else if (P.s + K != wb) {
+            return false;
+        }
+        if (P.w1 > ULEAF || P.w2 > ULEAF || (P.s & 1) || (P.w1 & 1) || (P.w2 & 1) || P.w1 < 2) return false;
+        pt.p[pt.count++] = P;
+    }
+    if (pt.count == 0 || pt.p[0].s != wa) return false;
+    for (int k = 0; k + 1 < pt.count; ++k) {
+        if (pt.p[k + 1].s != pt.p[k].s + pt.p[k].w1 + pt.p[k].w2) return false;
+        pt.p[k].nw = pt.p[k + 1].w1 + pt.p[k + 1].w2;
+    }
+    return true;
+}
+
 }  // namespace slk
 
 using namespace slk;
@@ -724,8 +759,11 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
     if (!attr_set) {
         SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gptq_window<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WindowSmem)));
+        SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gptq_window2),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Window2Smem)));
         attr_set = true;
     }
+    const bool periods_ok = n % 2 == 0 && (uintptr_t)U % 16 == 0 && getenv("SLK_NO_WINDOW2") == nullptr && dbg == 0;
 
     SLK_RUN("permute_in", 0, 8.0 * R * n, s, k_permute_in<<<R < 2048 ? R : 2048, 256, 0, s>>>(W, scale, order, R, n, Qp, inv_order));
 
@@ -771,7 +809,12 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
                     }
                 }
                 const double wbytes = 12.0 * R * (st.b - st.a) + ub;  // Q in/out + E out, U once
-                if (in_lds)
+                PeriodTable pt;
+                if (in_lds && periods_ok && st.ops.size() <= (size_t)MAX_OPS && as_periods(st.ops, st.a, st.b, pt))
+                    SLK_RUN("gptq_window", fl * R, wbytes, s,
+                            k_gptq_window2<<<row_tiles, 512, sizeof(Window2Smem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g, inv_step,
+                                                                                      fast_ok, pt));
+                else if (in_lds)
                     SLK_RUN("gptq_window", fl * R, wbytes, s,
                             k_gptq_window<true><<<row_tiles, 512, sizeof(WindowSmem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g,
                                                                                         inv_step, fast_ok, dbg, tab));

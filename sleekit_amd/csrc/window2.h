@@ -1,0 +1,361 @@
+// The window kernel for the reference's standard schedules: row-independent chain waves.
+//
+// A window (<= 512 columns of the permuted layer, 16 rows per workgroup) is a sequence of PERIODS:
+//   LEAF(s, w1) [ UPDATE(s, w1 -> w2) LEAF(s + w1, w2) ]   then   UPDATE(s, K = w1 + w2 -> rest of the window)
+// with w1, w2 <= 32 (obq.py:121-137 with min_block_size <= 32: n = 768 ... 11008 all give this).
+// Rows never interact, so a CHAIN wave (waves 0-3, four rows each, lane = (row, column mod 16))
+// runs its rows through a whole period alone: the leaf chain in registers, then the update of the
+// columns it needs next (the other leaf of the period, the next period) with
+// v_mfma_f64_4x4x4_4b_f64, whose result layout -- lane 16 i + c holds row i, column c -- is the
+// leaf's own.  That instruction, v_mfma_f64_16x16x4_f64 and a chain of v_fma_f64 over k all round
+// identically (tools/scratch/mfma4b.hip: bit-equal for K = 4 ... 512), so who computes which
+// columns is free.  The HELPER waves (4-7) feed the chain waves through LDS (leaf tables and the
+// U blocks of the local updates, one period ahead) and fold the rest of each period's update,
+// the columns beyond the next period, in behind their back on the 16-row MFMA.  One barrier per period:
+//
+//   chain:    [leaves of period p] B_p [update of period p+1's columns][leaves of period p+1] B_p+1 ...
+//   helpers:  ... B_p [rest of period p's update; tables, blocks for period p+2 / update p+1] B_p+1 ...
+#pragma once
+
+namespace slk {
+
+constexpr int ERING = 128;  // columns of E kept in LDS (two periods)
+constexpr int MAXP = 32;    // periods per window
+
+struct Period {
+    int s, w1, w2, nw;  // start column, leaf widths (w2 = 0: one leaf), width of the next period (0: last)
+};
+struct PeriodTable {
+    int count;
+    Period p[MAXP];
+};
+
+struct Window2Smem {
+    LeafTables lt[2][2];     // [period parity][leaf]
+    double sblk[2][16 * 64]; // U block of the update between the two leaves, in chunks of 4 k x 16 columns
+    double nblk[2][64 * 64]; // U block of the update into the next period, same chunking
+    float q[RB][WPITCH];
+    float e[RB][ERING + 4];
+    int odd[2][2][4];        // [parity][leaf][helper wave]: a diagonal defeats the exact-division shortcut
+};
+
+// The leaf chain on registers (see leaf_registers).  FAST: Markstein divisions (exact unless a
+// significand is all ones, which the caller has excluded); otherwise true divides.
+template <int NSTEP, bool FAST>
+__device__ __forceinline__ void leaf_chain(const LeafTables &lt, int c16, float &x0, float &x1, float &q0, float &q1,
+                                           float &e0, float &e1, const Grid g, float inv_step) {
+    double u0n = lt.u[0][c16], u1n = lt.u[0][c16 + 16], uiin = lt.udr[0][0], riin = lt.udr[0][1];
+    static_for<0, NSTEP>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const double u0 = u0n, u1 = u1n, uii = uiin, rii = riin;
+        if constexpr (i + 1 < NSTEP) {
+            u0n = lt.u[i + 1][c16];
+            u1n = lt.u[i + 1][c16 + 16];
+            uiin = lt.udr[i + 1][0];
+            riin = lt.udr[i + 1][1];
+        }
+        asm volatile("" : "+v"(x0), "+v"(x1)::"memory");  // the reads above are issued before step i starts
+        constexpr int src = i & 15;
+        const float xi = row_bcast<src>(i < 16 ? x0 : x1);
+        float q;
+        double err;
+        if (FAST) {
+            q = grid_value_fast(xi, g, inv_step);
+            const double d = (double)(xi - q);
+            const double qq = d * rii;
+            const double rem = __builtin_fma(-uii, qq, d);
+            err = __builtin_fma(rem, rii, qq);
+        } else {
+            q = grid_value(xi, g);
+            err = (double)(xi - q) / uii;
+        }
+        const float ef = (float)err;
+        const bool here = c16 == src;
+        if (i < 16) {
+            q0 = here ? q : q0;
+            e0 = here ? ef : e0;
+        } else {
+            q1 = here ? q : q1;
+            e1 = here ? ef : e1;
+        }
+        if (i < 15) x0 = (float)((double)x0 - err * u0);
+        if (NSTEP > 16) x1 = (float)((double)x1 - err * u1);
+    });
+}
+
+__global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, float *__restrict__ Eg,
+                                                      const double *__restrict__ U, int R, int n, int w0, int w1,
+                                                      Grid g, float inv_step, int fast_ok, PeriodTable tab) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Window2Smem &sm = *reinterpret_cast<Window2Smem *>(smem_raw);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool helper = wave >= 4;
+    const int ht = t - 256;
+    const int r0 = blockIdx.x * RB;
+    const int np = tab.count;
+    const int width = w1 - w0;
+    auto ring = [&](int c) { return (c - w0) & (ERING - 1); };
+
+    // columns [c_lo, c_hi) of the Q tile, global -> LDS, by `nth` threads of which this is number `tid`
+    auto load_cols = [&](int c_lo, int c_hi, int tid, int nth) {
+        const int cw = c_hi - c_lo;
+        for (int e = tid; e < RB * cw; e += nth) {
+            const int r = e / cw, c = c_lo + e % cw;
+            sm.q[r][c - w0] = (r0 + r < R) ? Qp[(size_t)(r0 + r) * n + c] : 0.0f;
+        }
+    };
+    const Period P0 = tab.p[0];
+    const int end0 = P0.s + P0.w1 + P0.w2;
+
+    if (!helper) {
+        // ======================================================== chain waves
+        const int c16 = lane & 15, rg = lane >> 4, row = 4 * wave + rg;
+        const bool row_live = r0 + row < R;
+        // Q[rows, dst0 : dst0 + N] -= E[rows, src0 : src0 + K] @ (U block in `chunks`), this wave's four rows.
+        // A operand: lane 16 k + 4 q + i carries E[i][k] (the same for the four column quads q);
+        // B operand: lane 16 k + c carries U[k][c]: chunk (cg, ks) is read as 512 contiguous bytes.
+        auto local_update = [&](const double *chunks, int src0, int K, int dst0, int N) {
+            const int ncg = (N + 15) >> 4, nks = (K + 3) >> 2;
+            const int ai = lane & 3, ak = lane >> 4;
+            const float *erow = &sm.e[4 * wave + ai][0];
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            auto body = [&](auto nks_c, auto ncg_c) {
+                constexpr int NKS = decltype(nks_c)::value, NCG = decltype(ncg_c)::value;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const double a = (double)erow[ring(src0 + 4 * ks + ak)];
+#pragma unroll
+                    for (int cg = 0; cg < NCG; ++cg)
+                        acc[cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, chunks[(size_t)(cg * NKS + ks) * 64 + lane], acc[cg], 0, 0, 0);
+                }
+            };
+            using std::integral_constant;
+            if (K == 64 && ncg == 4) body(integral_constant<int, 16>{}, integral_constant<int, 4>{});
+            else if (K == 32 && ncg == 2) body(integral_constant<int, 8>{}, integral_constant<int, 2>{});
+            else {
+                for (int ks = 0; ks < nks; ++ks) {
+                    const int kk = src0 + 4 * ks + ak;
+                    const float ev = erow[ring(min(kk, src0 + K - 1))];
+                    const double a = kk < src0 + K ? (double)ev : 0.0;
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg)
+                        if (cg < ncg)
+                            acc[cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, chunks[(size_t)(cg * nks + ks) * 64 + lane], acc[cg], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) {
+                const int col = dst0 + 16 * cg + c16;
+                if (cg < ncg && col < dst0 + N) sm.q[row][col - w0] = (float)((double)sm.q[row][col - w0] - acc[cg]);
+            }
+        };
+
+        load_cols(w0, end0, t, 512);  // with the helpers' half
+        __syncthreads();  // B_start
+        for (int p = 0; p < np; ++p) {
+            const Period P = tab.p[p];
+            const int par = p & 1;
+#pragma unroll 1
+            for (int lf = 0; lf < 2; ++lf) {
+                const int w = lf ? P.w2 : P.w1;
+                if (w == 0) break;
+                const int a = lf ? P.s + P.w1 : P.s;
+                if (lf) local_update(sm.sblk[par], P.s, P.w1, a, w);
+                const LeafTables &lt = sm.lt[par][lf];
+                const bool fast = fast_ok && (sm.odd[par][lf][0] | sm.odd[par][lf][1] | sm.odd[par][lf][2] | sm.odd[par][lf][3]) == 0;
+                const bool m0 = c16 < w, m1 = c16 + 16 < w;
+                float x0 = m0 ? sm.q[row][a - w0 + c16] : 0.0f, x1 = m1 ? sm.q[row][a - w0 + 16 + c16] : 0.0f;
+                float q0 = 0.0f, q1 = 0.0f, e0 = 0.0f, e1 = 0.0f;
+                if (!fast) leaf_chain<32, false>(lt, c16, x0, x1, q0, q1, e0, e1, g, inv_step);
+                else if (w <= 16) leaf_chain<16, true>(lt, c16, x0, x1, q0, q1, e0, e1, g, inv_step);
+                else leaf_chain<32, true>(lt, c16, x0, x1, q0, q1, e0, e1, g, inv_step);
+                if (m0) {
+                    sm.q[row][a - w0 + c16] = q0;
+                    sm.e[row][ring(a + c16)] = e0;
+                    if (row_live) Eg[(size_t)(r0 + row) * n + a + c16] = e0;
+                }
+                if (m1) {
+                    sm.q[row][a - w0 + 16 + c16] = q1;
+                    sm.e[row][ring(a + 16 + c16)] = e1;
+                    if (row_live) Eg[(size_t)(r0 + row) * n + a + 16 + c16] = e1;
+                }
+            }
+            __syncthreads();  // B_p
+            if (P.nw) local_update(sm.nblk[par], P.s, P.w1 + P.w2, P.s + P.w1 + P.w2, P.nw);
+        }
+    } else {
+        // ======================================================== helper waves
+        // leaf tables: registers <- U during one interval, LDS <- registers during the next
+        double pu[2][4];
+        auto fetch_tables = [&](int p) {  // both leaves of period p
+            if (p >= np) return;
+            const Period P = tab.p[p];
+#pragma unroll
+            for (int lf = 0; lf < 2; ++lf) {
+                const int a = lf ? P.s + P.w1 : P.s, w = max(1, lf ? P.w2 : P.w1);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int e = ht + 256 * h, i = min(e >> 5, w - 1), j = min(e & 31, w - 1);
+                    pu[lf][h] = U[(size_t)(a + i) * n + a + j];  // clamped, selected when written
+                }
+            }
+        };
+        auto write_tables = [&](int p) {
+            if (p >= np) return;
+            const Period P = tab.p[p];
+#pragma unroll
+            for (int lf = 0; lf < 2; ++lf) {
+                LeafTables &lt = sm.lt[p & 1][lf];
+                const int w = lf ? P.w2 : P.w1;
+                bool odd = false;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int e = ht + 256 * h, i = e >> 5, j = e & 31;
+                    const bool in = i < w && j < w;
+                    lt.u[i][j] = (in && j > i) ? pu[lf][h] : 0.0;
+                    if (i == j) {
+                        const double dg = in ? pu[lf][h] : 1.0;
+                        lt.udr[i][0] = dg;
+                        lt.udr[i][1] = 1.0 / dg;
+                        odd = odd || (__double_as_longlong(dg) & 0xFFFFFFFFFFFFFLL) == 0xFFFFFFFFFFFFFLL;
+                    }
+                }
+                const bool any = __builtin_amdgcn_ballot_w64(odd) != 0;
+                if (lane == 0) sm.odd[p & 1][lf][wave - 4] = any ? 1 : 0;
+            }
+        };
+        // U[a : a + K, lo : lo + N] -> chunks (cg * nks + ks) of (4 k) x (16 columns) doubles, straight
+        // into LDS (global_load_lds_dwordx4: 64 lanes x 16 bytes = two chunks per instruction, no
+        // registers).  Out-of-range rows and columns are clamped: their products meet a zero E
+        // operand or land in columns that are never stored.
+        auto stage_block = [&](double *chunks, int a, int K, int lo, int N) {
+            const int ncg = (N + 15) >> 4, nks = (K + 3) >> 2, total = ncg * nks;
+            const int half = lane >> 5, k = (lane >> 3) & 3, piece = lane & 7;
+            for (int pr = wave - 4; 2 * pr < total; pr += 4) {
+                const int ch = min(2 * pr + half, total - 1);
+                const int cg = ch / nks, ks = ch - cg * nks;
+                const int row = min(a + 4 * ks + k, a + K - 1);
+                const int col = min(lo + 16 * cg + 2 * piece, lo + N - 2);
+                __builtin_amdgcn_global_load_lds(U + (size_t)row * n + col, chunks + (size_t)pr * 128, 16, 0, 0);
+            }
+        };
+
+        // ---- the 16-row MFMA update of v1 on four waves: Q[:, lo:hi] -= E[:, a:b] @ U[a:b, lo:hi]
+        const int lr = lane & 15, lk = lane >> 4;
+        double cur[16];
+        auto load_round = [&](int a, int b, int lo, int hi, int blk, int kc, double(&bv)[16]) {
+            const int cc = min(lo + blk * 16 + lr, hi - 1);
+#pragma unroll
+            for (int s4 = 0; s4 < 16; ++s4) {
+                const int k = a + 64 * kc + 4 * s4 + lk;
+                bv[s4] = U[(size_t)min(k, b - 1) * n + cc];
+            }
+        };
+        auto mac_round = [&](int a, int b, int kc, const double(&bv)[16], double4_t &acc) {
+            const int kbase = a + 64 * kc, kcount = min(64, b - kbase);
+            if ((kcount == 64 || kcount == 32) && ((kbase - w0) & 31) == 0) {
+                const float *ep = &sm.e[lr][ring(kbase) + lk];  // 32-aligned: the chunk does not wrap
+                float av[16];
+#pragma unroll
+                for (int s4 = 0; s4 < 8; ++s4) av[s4] = ep[4 * s4];
+                if (kcount == 64) {
+#pragma unroll
+                    for (int s4 = 8; s4 < 16; ++s4) av[s4] = ep[4 * s4];
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < 8; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[s4], bv[s4], acc, 0, 0, 0);
+                if (kcount == 64) {
+#pragma unroll
+                    for (int s4 = 8; s4 < 16; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[s4], bv[s4], acc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s4 = 0; s4 < 16; ++s4) {
+                    const int k = kbase + 4 * s4 + lk;
+                    const float ev = sm.e[lr][ring(min(k, b - 1))];
+                    const double av = k < b ? (double)ev : 0.0;
+                    if (4 * s4 < kcount) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[s4], acc, 0, 0, 0);
+                }
+            }
+        };
+        auto store_block = [&](int lo, int hi, int blk, const double4_t &acc) {
+            const int col = lo + blk * 16 + lr;
+            if (col < hi) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = lk + 4 * r;
+                    sm.q[rr][col - w0] = (float)((double)sm.q[rr][col - w0] - acc[r]);
+                }
+            }
+        };
+        auto run_update = [&](int a, int b, int lo, int hi, int wid, int nw) {
+            const int nblk = (hi - lo + 15) / 16, nchunk = (b - a + 63) / 64;
+            if (wid >= nblk) return;
+            const int nr = (nblk - wid + nw - 1) / nw * nchunk;
+            double other[16];
+            load_round(a, b, lo, hi, wid, 0, cur);
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+            const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+            int blk = wid, kc = 0;
+            for (int r = 0; r < nr; r += 2) {
+                int blk1 = blk, kc1 = kc + 1;
+                if (kc1 == nchunk) kc1 = 0, blk1 += nw;
+                const bool has1 = r + 1 < nr;
+                if (has1) load_round(a, b, lo, hi, blk1, kc1, other);
+                mac_round(a, b, kc, cur, acc);
+                if (kc + 1 == nchunk) {
+                    store_block(lo, hi, blk, acc);
+                    acc = zero4;
+                }
+                if (!has1) break;
+                int blk2 = blk1, kc2 = kc1 + 1;
+                if (kc2 == nchunk) kc2 = 0, blk2 += nw;
+                if (r + 2 < nr) load_round(a, b, lo, hi, blk2, kc2, cur);
+                mac_round(a, b, kc1, other, acc);
+                if (kc1 + 1 == nchunk) {
+                    store_block(lo, hi, blk1, acc);
+                    acc = zero4;
+                }
+                blk = blk2, kc = kc2;
+            }
+        };
+
+        // ---- prologue: tables and the inner block of period 0
+        fetch_tables(0);
+        load_cols(w0, end0, t, 512);  // with the chain waves' half
+        if (P0.w2) stage_block(sm.sblk[0], P0.s, P0.w1, P0.s + P0.w1, P0.w2);
+        write_tables(0);
+        fetch_tables(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // B_start
+        for (int p = 0; p < np; ++p) {
+            // interval I_p, while the chain waves run period p
+            const Period P = tab.p[p];
+            const int K = P.w1 + P.w2;
+            if (P.nw) stage_block(sm.nblk[p & 1], P.s, K, P.s + K, P.nw);
+            if (p + 1 < np) {
+                const Period N1 = tab.p[p + 1];
+                if (N1.w2) stage_block(sm.sblk[(p + 1) & 1], N1.s, N1.w1, N1.s + N1.w1, N1.w2);
+            }
+            if (p == 0) load_cols(end0, w1, ht, 256);  // the rest of the tile
+            write_tables(p + 1);
+            fetch_tables(p + 2);
+            if (p >= 1) {
+                // the rest of period p-1's update: beyond period p, whose columns the chain waves have done
+                const Period M = tab.p[p - 1];
+                const int lo = P.s + K;
+                if (lo < w1) run_update(M.s, M.s + M.w1 + M.w2, lo, w1, wave - 4, 4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // B_p
+        }
+    }
+
+    // every column is final: the tile goes back (E went out leaf by leaf)
+    for (int e = t; e < RB * width; e += 512) {
+        const int r = e / width, c = e % width;
+        if (r0 + r < R) Qp[(size_t)(r0 + r) * n + w0 + c] = sm.q[r][c];
+    }
+}
+
+}  // namespace slk

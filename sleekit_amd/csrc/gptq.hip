@@ -685,7 +685,7 @@ using namespace slk;
 namespace slk {
 // the leaf chain alone: `iters` leaves of 32 columns on the tables of a made-up block; out[0] = cycles
 // of wave 0, out[1] = checksum.  blockDim = 256 (one wave per SIMD) or 512 (two).
-__global__ void k_probe_leaf(double *out, int iters, Grid g, float inv_step) {
+__global__ void k_probe_leaf(double *out, int iters, int mode, Grid g, float inv_step) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     WindowSmem &sm = *reinterpret_cast<WindowSmem *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -697,23 +697,45 @@ __global__ void k_probe_leaf(double *out, int iters, Grid g, float inv_step) {
     for (int e = t; e < RB * 64; e += blockDim.x) sm.q[e >> 6][e & 63] = 0.37f * ((e * 13) % 17 - 8);
     __syncthreads();
     const long long t0 = (long long)__builtin_readcyclecounter();
-    for (int it = 0; it < iters; ++it) leaf_registers<32>(sm, sm.lt[0], wave & 3, lane, (it & 1) * 32, 32, g, inv_step);
+    double4_t macc = {0, 0, 0, 0};
+    double vacc = 1.0;
+    // modes 1-3: leaf waves 0-3, companions 4-7 (same SIMDs if waves go round the SIMDs);
+    // mode 4: leaf waves 0, 1, 4, 5 and MFMA companions 2, 3, 6, 7 (other SIMDs under that mapping)
+    const bool leafer = mode == 4 ? (wave & 2) == 0 : wave < 4;
+    if (mode == 4) mode = leafer ? 0 : 1;
+    if (t == 0) out[2] = (double)__builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 4);  // HW_ID, 32 bits... low 16 here
+    if (leafer || mode == 0) {
+        for (int it = 0; it < iters; ++it) leaf_registers<32>(sm, sm.lt[0], (wave & 1) + ((wave >> 2) << 1), lane, (it & 1) * 32, 32, g, inv_step);
+    } else if (mode == 1) {
+        // companion wave on the same SIMD: back-to-back 16x16x4 MFMAs for about as long
+        for (int it = 0; it < iters * 64; ++it) macc = __builtin_amdgcn_mfma_f64_16x16x4f64(1.0 + lane, 2.0, macc, 0, 0, 0);
+    } else if (mode == 2) {
+        // companion wave: a dependent float64 fma chain
+        for (int it = 0; it < iters * 400; ++it) vacc = __builtin_fma(vacc, 1.0000001, 1e-9);
+    } else {
+        // companion wave: LDS reads
+        for (int it = 0; it < iters * 100; ++it) vacc += sm.lt[1].u[(it + lane) & 31][lane & 31];
+    }
     const long long t1 = (long long)__builtin_readcyclecounter();
     __syncthreads();
     if (t == 0) {
         out[0] = (double)(t1 - t0);
         out[1] = sm.q[3][5] + sm.e[2][7];
     }
+    if (macc[0] + vacc == 1.2345e-30) out[1] = macc[0];
 }
 }  // namespace slk
 
 extern "C" int slk_probe_leaf_chain(double *out, int iters, int waves_per_simd, slk_stream_t stream) {
-    SLK_REQUIRE(out && iters > 0 && (waves_per_simd == 1 || waves_per_simd == 2), "bad arguments");
+    // waves_per_simd: 1, 2 (all leaf waves), or 2 + 10 * mode for companions (1 MFMA, 2 fma chain, 3 LDS reads)
+    const int mode = waves_per_simd / 10;
+    waves_per_simd %= 10;
+    SLK_REQUIRE(out && iters > 0 && (waves_per_simd == 1 || waves_per_simd == 2) && mode >= 0 && mode <= 4, "bad arguments");
     hipStream_t s = as_stream(stream);
     const Grid g = make_grid(8, -1.0, 1.0);
     SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_probe_leaf), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)sizeof(WindowSmem)));
-    SLK_RUN("probe_leaf", 0, 0, s, k_probe_leaf<<<1, 256 * waves_per_simd, sizeof(WindowSmem), s>>>(out, iters, g, 1.0f / g.step));
+    SLK_RUN("probe_leaf", 0, 0, s, k_probe_leaf<<<1, 256 * waves_per_simd, sizeof(WindowSmem), s>>>(out, iters, mode, g, 1.0f / g.step));
     return SLK_OK;
 }
 
@@ -763,7 +785,7 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Window2Smem)));
         attr_set = true;
     }
-    const bool periods_ok = n % 2 == 0 && (uintptr_t)U % 16 == 0 && getenv("SLK_NO_WINDOW2") == nullptr && dbg == 0;
+    const bool periods_ok = n % 2 == 0 && (uintptr_t)U % 16 == 0 && getenv("SLK_NO_WINDOW2") == nullptr && (dbg & ~24) == 0;
 
     SLK_RUN("permute_in", 0, 8.0 * R * n, s, k_permute_in<<<R < 2048 ? R : 2048, 256, 0, s>>>(W, scale, order, R, n, Qp, inv_order));
 
@@ -813,7 +835,7 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
                 if (in_lds && periods_ok && st.ops.size() <= (size_t)MAX_OPS && as_periods(st.ops, st.a, st.b, pt))
                     SLK_RUN("gptq_window", fl * R, wbytes, s,
                             k_gptq_window2<<<row_tiles, 512, sizeof(Window2Smem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g, inv_step,
-                                                                                      fast_ok, pt));
+                                                                                      fast_ok, dbg & 24, pt));
                 else if (in_lds)
                     SLK_RUN("gptq_window", fl * R, wbytes, s,
                             k_gptq_window<true><<<row_tiles, 512, sizeof(WindowSmem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g,

@@ -85,23 +85,52 @@ __device__ __forceinline__ void leaf_chain(const LeafTables &lt, int c16, float 
 
 __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, float *__restrict__ Eg,
                                                       const double *__restrict__ U, int R, int n, int w0, int w1,
-                                                      Grid g, float inv_step, int fast_ok, PeriodTable tab) {
+                                                      Grid g, float inv_step, int fast_ok, int prof, PeriodTable tab) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Window2Smem &sm = *reinterpret_cast<Window2Smem *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const bool helper = wave >= 4;
-    const int ht = t - 256;
+    // cycle accounting (debug, SLK_WIN_DBG bit 3): wave-uniform, workgroup 0, waves 0 and 4
+    const bool timing = (prof & 8) && blockIdx.x == 0;
+    long long tmark = timing ? (long long)__builtin_readcyclecounter() : 0;
+    const long long tstart = tmark;
+    long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto lap = [&](int slot) {
+        if (timing) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            tacc[slot] += now - tmark;
+            tmark = now;
+        }
+    };
+    // Waves go round the four SIMDs (wave i on SIMD i % 4), and the float64 MFMA runs on the same units
+    // as float64 vector arithmetic: a wave issuing MFMAs doubles the time of a leaf chain on ITS SIMD
+    // (tools/micro_leaf.py: 125 -> 254 cycles a column), while two chains share a SIMD at no cost
+    // (latency-bound).  So the chain waves are 0, 1, 4, 5 (SIMDs 0-1), the helpers 2, 3, 6, 7 (SIMDs 2-3).
+    const bool helper = (wave & 2) != 0;
+    const int role_wave = (wave & 1) + ((wave >> 2) << 1);  // 0-3 within the role
+    const int ht = role_wave * 64 + lane;                   // thread index within the role, 0-255
     const int r0 = blockIdx.x * RB;
     const int np = tab.count;
     const int width = w1 - w0;
     auto ring = [&](int c) { return (c - w0) & (ERING - 1); };
 
-    // columns [c_lo, c_hi) of the Q tile, global -> LDS, by `nth` threads of which this is number `tid`
+    // columns [c_lo, c_hi) of the Q tile, global -> LDS, by `nth` threads of which this is number `tid`;
+    // eight loads in flight per thread (a load-wait-store loop pays the full latency per element)
     auto load_cols = [&](int c_lo, int c_hi, int tid, int nth) {
-        const int cw = c_hi - c_lo;
-        for (int e = tid; e < RB * cw; e += nth) {
-            const int r = e / cw, c = c_lo + e % cw;
-            sm.q[r][c - w0] = (r0 + r < R) ? Qp[(size_t)(r0 + r) * n + c] : 0.0f;
+        const int cw = c_hi - c_lo, total = RB * cw;
+        for (int e0 = tid; e0 < total; e0 += 8 * nth) {
+            float v[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const int e = min(e0 + h * nth, total - 1);
+                const int r = e / cw, c = c_lo + e % cw;
+                v[h] = Qp[(size_t)min(r0 + r, R - 1) * n + c];
+            }
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const int e = e0 + h * nth;
+                const int r = e / cw, c = c_lo + e % cw;
+                if (e < total) sm.q[r][c - w0] = (r0 + r < R) ? v[h] : 0.0f;
+            }
         }
     };
     const Period P0 = tab.p[0];
@@ -109,7 +138,7 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
 
     if (!helper) {
         // ======================================================== chain waves
-        const int c16 = lane & 15, rg = lane >> 4, row = 4 * wave + rg;
+        const int c16 = lane & 15, rg = lane >> 4, row = 4 * role_wave + rg;
         const bool row_live = r0 + row < R;
         // Q[rows, dst0 : dst0 + N] -= E[rows, src0 : src0 + K] @ (U block in `chunks`), this wave's four rows.
         // A operand: lane 16 k + 4 q + i carries E[i][k] (the same for the four column quads q);
@@ -117,7 +146,7 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
         auto local_update = [&](const double *chunks, int src0, int K, int dst0, int N) {
             const int ncg = (N + 15) >> 4, nks = (K + 3) >> 2;
             const int ai = lane & 3, ak = lane >> 4;
-            const float *erow = &sm.e[4 * wave + ai][0];
+            const float *erow = &sm.e[4 * role_wave + ai][0];
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             auto body = [&](auto nks_c, auto ncg_c) {
                 constexpr int NKS = decltype(nks_c)::value, NCG = decltype(ncg_c)::value;
@@ -152,6 +181,7 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
 
         load_cols(w0, end0, t, 512);  // with the helpers' half
         __syncthreads();  // B_start
+        lap(0);
         for (int p = 0; p < np; ++p) {
             const Period P = tab.p[p];
             const int par = p & 1;
@@ -161,6 +191,7 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                 if (w == 0) break;
                 const int a = lf ? P.s + P.w1 : P.s;
                 if (lf) local_update(sm.sblk[par], P.s, P.w1, a, w);
+                lap(2);
                 const LeafTables &lt = sm.lt[par][lf];
                 const bool fast = fast_ok && (sm.odd[par][lf][0] | sm.odd[par][lf][1] | sm.odd[par][lf][2] | sm.odd[par][lf][3]) == 0;
                 const bool m0 = c16 < w, m1 = c16 + 16 < w;
@@ -179,9 +210,12 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                     sm.e[row][ring(a + 16 + c16)] = e1;
                     if (row_live) Eg[(size_t)(r0 + row) * n + a + 16 + c16] = e1;
                 }
+                lap(1);
             }
             __syncthreads();  // B_p
+            lap(3);
             if (P.nw) local_update(sm.nblk[par], P.s, P.w1 + P.w2, P.s + P.w1 + P.w2, P.nw);
+            lap(2);
         }
     } else {
         // ======================================================== helper waves
@@ -207,38 +241,69 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
             for (int lf = 0; lf < 2; ++lf) {
                 LeafTables &lt = sm.lt[p & 1][lf];
                 const int w = lf ? P.w2 : P.w1;
-                bool odd = false;
+                // a thread meets at most one diagonal slot (e = 33 i) per leaf: one division, not four
+                double dgv = 1.0;
+                int di = -1;
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const int e = ht + 256 * h, i = e >> 5, j = e & 31;
                     const bool in = i < w && j < w;
                     lt.u[i][j] = (in && j > i) ? pu[lf][h] : 0.0;
                     if (i == j) {
-                        const double dg = in ? pu[lf][h] : 1.0;
-                        lt.udr[i][0] = dg;
-                        lt.udr[i][1] = 1.0 / dg;
-                        odd = odd || (__double_as_longlong(dg) & 0xFFFFFFFFFFFFFLL) == 0xFFFFFFFFFFFFFLL;
+                        dgv = in ? pu[lf][h] : 1.0;
+                        di = i;
                     }
                 }
+                bool odd = false;
+                if (di >= 0) {
+                    lt.udr[di][0] = dgv;
+                    lt.udr[di][1] = 1.0 / dgv;
+                    odd = (__double_as_longlong(dgv) & 0xFFFFFFFFFFFFFLL) == 0xFFFFFFFFFFFFFLL;
+                }
                 const bool any = __builtin_amdgcn_ballot_w64(odd) != 0;
-                if (lane == 0) sm.odd[p & 1][lf][wave - 4] = any ? 1 : 0;
+                if (lane == 0) sm.odd[p & 1][lf][role_wave] = any ? 1 : 0;
             }
         };
-        // U[a : a + K, lo : lo + N] -> chunks (cg * nks + ks) of (4 k) x (16 columns) doubles, straight
-        // into LDS (global_load_lds_dwordx4: 64 lanes x 16 bytes = two chunks per instruction, no
-        // registers).  Out-of-range rows and columns are clamped: their products meet a zero E
-        // operand or land in columns that are never stored.
-        auto stage_block = [&](double *chunks, int a, int K, int lo, int N) {
+        // U[a : a + K, lo : lo + N] -> chunks (cg * nks + ks) of (4 k) x (16 columns) doubles in LDS, through
+        // registers: the loads are issued at the start of an interval, the LDS writes come at its end.
+        // (global_load_lds would need no registers, but the compiler then makes every LDS read wait
+        // for all loads in flight -- it cannot tell the two apart -- which serialises the MFMA rounds.)
+        // Thread (role_wave, lane) of step `it` carries 16 bytes of chunk 2 (role_wave + 4 it) + (lane >> 5).
+        // Out-of-range rows and columns are clamped: their products meet a zero E operand or land in
+        // columns that are never stored.
+        typedef double double2_t __attribute__((ext_vector_type(2)));
+        auto stage_fetch = [&](auto steps_c, double2_t *regs, int a, int K, int lo, int N) {
+            constexpr int STEPS = decltype(steps_c)::value;
             const int ncg = (N + 15) >> 4, nks = (K + 3) >> 2, total = ncg * nks;
             const int half = lane >> 5, k = (lane >> 3) & 3, piece = lane & 7;
-            for (int pr = wave - 4; 2 * pr < total; pr += 4) {
-                const int ch = min(2 * pr + half, total - 1);
-                const int cg = ch / nks, ks = ch - cg * nks;
-                const int row = min(a + 4 * ks + k, a + K - 1);
-                const int col = min(lo + 16 * cg + 2 * piece, lo + N - 2);
-                __builtin_amdgcn_global_load_lds(U + (size_t)row * n + col, chunks + (size_t)pr * 128, 16, 0, 0);
+            int ch = 2 * role_wave + half;
+            int cg = ch / nks, ks = ch - cg * nks;
+            const double *colp = U + (size_t)a * n + lo;
+#pragma unroll
+            for (int it = 0; it < STEPS; ++it) {
+                const bool over = ch >= total;  // beyond the block: repeat the last chunk (never stored)
+                const int cgc = over ? ncg - 1 : cg, ksc = over ? nks - 1 : ks;
+                const int row = min(4 * ksc + k, K - 1);
+                const int col = min(16 * cgc + 2 * piece, N - 2);
+                regs[it] = *reinterpret_cast<const double2_t *>(colp + (size_t)row * n + col);
+                ch += 8;
+                ks += 8;
+                while (ks >= nks) ks -= nks, ++cg;
             }
         };
+        auto stage_store = [&](auto steps_c, const double2_t *regs, double *chunks, int K, int N) {
+            constexpr int STEPS = decltype(steps_c)::value;
+            const int total = ((N + 15) >> 4) * ((K + 3) >> 2);
+#pragma unroll
+            for (int it = 0; it < STEPS; ++it) {
+                const int pr = role_wave + 4 * it;
+                if (2 * pr + (lane >> 5) < total) *reinterpret_cast<double2_t *>(chunks + (size_t)pr * 128 + 2 * lane) = regs[it];
+            }
+        };
+        using std::integral_constant;
+        const integral_constant<int, 8> steps_n{};  // 64 x 64 block: 64 chunks = 32 pairs = 8 steps of 4 waves
+        const integral_constant<int, 2> steps_s{};  // 32 x 32 block: 16 chunks
+        double2_t nreg[8], sreg[2];
 
         // ---- the 16-row MFMA update of v1 on four waves: Q[:, lo:hi] -= E[:, a:b] @ U[a:b, lo:hi]
         const int lr = lane & 15, lk = lane >> 4;
@@ -288,10 +353,15 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                 }
             }
         };
+        // Rounds in pairs on two register buffers.  The loads of the round after next are issued
+        // UNCONDITIONALLY (clamped to the last round when there is none): with a fixed number of loads
+        // between a buffer's fill and its use the compiler can wait with vmcnt(16); a conditional
+        // load in the loop makes it fall back to vmcnt(0), which serialises load and MFMA.
         auto run_update = [&](int a, int b, int lo, int hi, int wid, int nw) {
             const int nblk = (hi - lo + 15) / 16, nchunk = (b - a + 63) / 64;
             if (wid >= nblk) return;
             const int nr = (nblk - wid + nw - 1) / nw * nchunk;
+            const int last_blk = wid + ((nblk - wid - 1) / nw) * nw;
             double other[16];
             load_round(a, b, lo, hi, wid, 0, cur);
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -301,20 +371,22 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                 int blk1 = blk, kc1 = kc + 1;
                 if (kc1 == nchunk) kc1 = 0, blk1 += nw;
                 const bool has1 = r + 1 < nr;
-                if (has1) load_round(a, b, lo, hi, blk1, kc1, other);
+                load_round(a, b, lo, hi, has1 ? blk1 : last_blk, has1 ? kc1 : nchunk - 1, other);
                 mac_round(a, b, kc, cur, acc);
                 if (kc + 1 == nchunk) {
                     store_block(lo, hi, blk, acc);
                     acc = zero4;
                 }
-                if (!has1) break;
                 int blk2 = blk1, kc2 = kc1 + 1;
                 if (kc2 == nchunk) kc2 = 0, blk2 += nw;
-                if (r + 2 < nr) load_round(a, b, lo, hi, blk2, kc2, cur);
-                mac_round(a, b, kc1, other, acc);
-                if (kc1 + 1 == nchunk) {
-                    store_block(lo, hi, blk1, acc);
-                    acc = zero4;
+                const bool has2 = r + 2 < nr;
+                load_round(a, b, lo, hi, has2 ? blk2 : last_blk, has2 ? kc2 : nchunk - 1, cur);
+                if (has1) {
+                    mac_round(a, b, kc1, other, acc);
+                    if (kc1 + 1 == nchunk) {
+                        store_block(lo, hi, blk1, acc);
+                        acc = zero4;
+                    }
                 }
                 blk = blk2, kc = kc2;
             }
@@ -323,31 +395,42 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
         // ---- prologue: tables and the inner block of period 0
         fetch_tables(0);
         load_cols(w0, end0, t, 512);  // with the chain waves' half
-        if (P0.w2) stage_block(sm.sblk[0], P0.s, P0.w1, P0.s + P0.w1, P0.w2);
+        if (P0.w2) {
+            stage_fetch(steps_s, sreg, P0.s, P0.w1, P0.s + P0.w1, P0.w2);
+            stage_store(steps_s, sreg, sm.sblk[0], P0.w1, P0.w2);
+        }
         write_tables(0);
         fetch_tables(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // B_start
+        lap(0);
         for (int p = 0; p < np; ++p) {
             // interval I_p, while the chain waves run period p
             const Period P = tab.p[p];
             const int K = P.w1 + P.w2;
-            if (P.nw) stage_block(sm.nblk[p & 1], P.s, K, P.s + K, P.nw);
-            if (p + 1 < np) {
-                const Period N1 = tab.p[p + 1];
-                if (N1.w2) stage_block(sm.sblk[(p + 1) & 1], N1.s, N1.w1, N1.s + N1.w1, N1.w2);
-            }
-            if (p == 0) load_cols(end0, w1, ht, 256);  // the rest of the tile
+            // registers first: a wait for the table values (fetched an interval ago) must not have the
+            // block loads below in front of it -- vmcnt completes in order
             write_tables(p + 1);
+            lap(6);
+            if (P.nw) stage_fetch(steps_n, nreg, P.s, K, P.s + K, P.nw);
+            const Period N1 = tab.p[min(p + 1, np - 1)];
+            const bool has_s = p + 1 < np && N1.w2;
+            if (has_s) stage_fetch(steps_s, sreg, N1.s, N1.w1, N1.s + N1.w1, N1.w2);
+            lap(4);
             fetch_tables(p + 2);
+            lap(10);
+            if (p == 0) load_cols(end0, w1, ht, 256);  // the rest of the tile
+            lap(11);
             if (p >= 1) {
                 // the rest of period p-1's update: beyond period p, whose columns the chain waves have done
                 const Period M = tab.p[p - 1];
                 const int lo = P.s + K;
-                if (lo < w1) run_update(M.s, M.s + M.w1 + M.w2, lo, w1, wave - 4, 4);
+                if (lo < w1) run_update(M.s, M.s + M.w1 + M.w2, lo, w1, role_wave, 4);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lap(5);
+            if (P.nw) stage_store(steps_n, nreg, sm.nblk[p & 1], K, P.nw);
+            if (has_s) stage_store(steps_s, sreg, sm.sblk[(p + 1) & 1], N1.w1, N1.w2);
             __syncthreads();  // B_p
+            lap(7);
         }
     }
 
@@ -355,6 +438,12 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
     for (int e = t; e < RB * width; e += 512) {
         const int r = e / width, c = e % width;
         if (r0 + r < R) Qp[(size_t)(r0 + r) * n + w0 + c] = sm.q[r][c];
+    }
+    if (timing && lane == 0 && (wave == 0 || wave == 2)) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            if (tacc[k] && k != 9) g_win_cycles[k] += tacc[k];
+        if (wave == 0) g_win_cycles[9] += (long long)__builtin_readcyclecounter() - tstart;
     }
 }
 

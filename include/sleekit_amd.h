@@ -194,7 +194,7 @@ int slk_probe_mfma_f64_acc(double *sink, int blocks, int iters, int nacc, slk_st
  * out[0] = shader cycles, out[1] = 100 MHz ticks, out[2] = checksum.                      */
 int slk_probe_chain(double *out, int iters, int mode, slk_stream_t stream);
 /* Debug: cycle counters of workgroup 0 of the window kernel, filled when SLK_WIN_DBG has bit 3 set.
- * host_out: 16 int64 on the HOST.  Synchronises the device.  No reference counterpart. */
+ * host_out: 80 int64 on the HOST (16 counters + 64 per-period entries of the standard-schedule kernel).  Synchronises the device.  No reference counterpart. */
 int slk_probe_window_cycles(long long *host_out, int reset);
 /* Debug: the leaf chain alone (32-column leaves, 8-level grid) on one workgroup with one or two waves per
  * SIMD.  out (DEVICE, 2 doubles): cycles wave 0 spent on `iters` leaves, checksum. */

@@ -181,6 +181,7 @@ __device__ __forceinline__ void leaf_registers(WindowSmem &sm, const LeafTables 
 
 // cycle counters of workgroup 0 (SLK_WIN_DBG bit 3), read back by slk_probe_window_cycles
 __device__ long long g_win_cycles[16];
+__device__ long long g_win_trace[64];  // window2: busy cycles per period, chain wave 0 / helper wave 2 (+32)
 
 // One workgroup = 512 threads = 8 waves = RB rows, Q and E of the window resident in LDS.
 //
@@ -743,9 +744,11 @@ extern "C" int slk_probe_window_cycles(long long *host_out, int reset) {
     SLK_REQUIRE(host_out, "null pointer");
     SLK_HIP(hipDeviceSynchronize());
     SLK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_win_cycles), sizeof(long long) * 16));
+    SLK_HIP(hipMemcpyFromSymbol(host_out + 16, HIP_SYMBOL(g_win_trace), sizeof(long long) * 64));
     if (reset) {
-        long long zero[16] = {0};
-        SLK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_win_cycles), zero, sizeof(zero)));
+        long long zero[64] = {0};
+        SLK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_win_cycles), zero, sizeof(long long) * 16));
+        SLK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_win_trace), zero, sizeof(zero)));
     }
     return SLK_OK;
 }

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
     long long tmark = timing ? (long long)__builtin_readcyclecounter() : 0;
     const long long tstart = tmark;
     long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tper = tmark;  // start of the current period / interval
     auto lap = [&](int slot) {
         if (timing) {
             const long long now = (long long)__builtin_readcyclecounter();
@@ -212,7 +213,9 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                 }
                 lap(1);
             }
+            if (timing && lane == 0 && wave == 0) g_win_trace[p] += (long long)__builtin_readcyclecounter() - tper;
             __syncthreads();  // B_p
+            tper = timing ? (long long)__builtin_readcyclecounter() : 0;
             lap(3);
             if (P.nw) local_update(sm.nblk[par], P.s, P.w1 + P.w2, P.s + P.w1 + P.w2, P.nw);
             lap(2);
@@ -429,7 +432,9 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
             lap(5);
             if (P.nw) stage_store(steps_n, nreg, sm.nblk[p & 1], K, P.nw);
             if (has_s) stage_store(steps_s, sreg, sm.sblk[(p + 1) & 1], N1.w1, N1.w2);
+            if (timing && lane == 0 && wave == 2) g_win_trace[32 + p] += (long long)__builtin_readcyclecounter() - tper;
             __syncthreads();  // B_p
+            tper = timing ? (long long)__builtin_readcyclecounter() : 0;
             lap(7);
         }
     }

@@ -11,7 +11,7 @@ W = torch.randn(R, n, device="cuda", generator=g) * 0.5
 U = torch.triu(torch.randn(n, n, device="cuda", dtype=torch.float64, generator=g) * 0.01) + torch.eye(n, device="cuda", dtype=torch.float64)
 order = torch.arange(n, device="cuda")
 cb = codebook.UniformCodebook(8, -1, 1)._abi()
-buf = (ctypes.c_longlong * 16)()
+buf = (ctypes.c_longlong * 80)()
 engine.run_loop(W, None, order, U, cb, 32, 8)
 _lib.check(_lib.lib.slk_probe_window_cycles(buf, 1))
 reps = 3
@@ -26,3 +26,8 @@ import os
 if not os.environ.get("SLK_NO_WINDOW2"): names = names2
 for k, name in names.items():
     print(f"  {name:<32s} {buf[k] / launches / 2400.0:8.2f} us per window launch")
+
+if not os.environ.get("SLK_NO_WINDOW2"):
+    print("  busy us per period (chain wave 0 | helper wave 2):")
+    for p in range(8):
+        print(f"    period {p}: {buf[16 + p] / launches / 2400.0:6.2f} | {buf[48 + p] / launches / 2400.0:6.2f}")

@@ -165,7 +165,7 @@ namespace slk {
 namespace {
 struct ProfEntry {
     const char *name;
-    double flops, bytes;
+    double flops, bytes, width;  // width: share of the chip's 256 CUs the launch can occupy
     hipEvent_t start, stop;
 };
 struct ProfState {
@@ -187,10 +187,15 @@ hipEvent_t prof_event() {
 }
 }  // namespace
 
+static thread_local long g_next_width = 0;
+void prof_next_width(long workgroups) { g_next_width = workgroups; }
+
 ProfScope::ProfScope(const char *name, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+    const long wgs = g_next_width;
+    g_next_width = 0;
     if (!g_prof.on) return;
     std::lock_guard<std::mutex> lock(g_prof.mu);
-    ProfEntry e{name, flops, bytes, prof_event(), prof_event()};
+    ProfEntry e{name, flops, bytes, wgs > 0 && wgs < 256 ? wgs / 256.0 : 1.0, prof_event(), prof_event()};
     if (!e.start || !e.stop) return;
     (void)hipEventRecord(e.start, s);
     g_prof.entries.push_back(e);
@@ -229,7 +234,7 @@ int slk_profile_report(char *buf, size_t cap) {
     std::lock_guard<std::mutex> lock(g_prof.mu);
     struct Agg {
         long n = 0;
-        double ms = 0, flops = 0, bytes = 0;
+        double ms = 0, flops = 0, bytes = 0, cu_ms = 0;
     };
     std::map<std::string, Agg> agg;
     std::vector<std::string> order;
@@ -241,6 +246,7 @@ int slk_profile_report(char *buf, size_t cap) {
         Agg &a = agg[e.name];
         a.n += 1;
         a.ms += ms;
+        a.cu_ms += ms * e.width;
         a.flops += e.flops;
         a.bytes += e.bytes;
     }
@@ -248,8 +254,8 @@ int slk_profile_report(char *buf, size_t cap) {
     char line[512];
     for (size_t i = 0; i < order.size(); ++i) {
         const Agg &a = agg[order[i]];
-        snprintf(line, sizeof(line), "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
-                 i ? ", " : "", order[i].c_str(), a.n, a.ms, a.flops, a.bytes);
+        snprintf(line, sizeof(line), "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"chip_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 i ? ", " : "", order[i].c_str(), a.n, a.ms, a.cu_ms, a.flops, a.bytes);
         out += line;
     }
     out += "]";

@@ -41,6 +41,11 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// Workgroups of the NEXT profiled launch, for launches that cannot fill the chip (a latency chain on
+// one workgroup is not "dominant" because it is long): the report weighs a launch's time by
+// min(1, workgroups / 256).  0 = not stated, taken as chip-wide.
+void prof_next_width(long workgroups);
+
 // SLK_RUN("kernel name", flops, bytes, stream, kernel<<<grid, block, smem, stream>>>(args...));
 #define SLK_RUN(name, flops, bytes, stream, ...)                 \
     do {                                                         \
@@ -49,6 +54,13 @@ struct ProfScope {
             __VA_ARGS__;                                         \
         }                                                        \
         SLK_LAUNCH_CHECK();                                      \
+    } while (0)
+
+// SLK_RUN for a launch of `wgs` workgroups (see prof_next_width)
+#define SLK_RUN_W(name, flops, bytes, wgs, stream, ...) \
+    do {                                                \
+        slk::prof_next_width((long)(wgs));              \
+        SLK_RUN(name, flops, bytes, stream, __VA_ARGS__); \
     } while (0)
 
 static inline hipStream_t as_stream(slk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

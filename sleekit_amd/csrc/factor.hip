@@ -303,14 +303,14 @@ extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, vo
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelSmem)));
         attr_set = true;
     }
-    SLK_RUN("clear_info", 0, 4, s, k_clear_info<<<1, 1, 0, s>>>(info));
+    SLK_RUN_W("clear_info", 0, 4, 1, s, k_clear_info<<<1, 1, 0, s>>>(info));
 
     for (int K0 = 0; K0 < ld; K0 += OUTER) {
         const int K1 = K0 + OUTER < ld ? K0 + OUTER : ld;
         for (int k0 = K0; k0 < K1; k0 += PANEL) {
             const int below = (ld - k0) / PANEL;  // tiles from the diagonal tile down
             // potf2 + inverse of the 64-tile (2/3 * 64^3) and the triangular product below it
-            SLK_RUN("chol_panel", 2.0 / 3.0 * 64 * 64 * 64 + (double)(below - 1) * 64 * 64 * 64, 16.0 * below * 64 * 64, s,
+            SLK_RUN_W("chol_panel", 2.0 / 3.0 * 64 * 64 * 64 + (double)(below - 1) * 64 * 64 * 64, 16.0 * below * 64 * 64, below, s,
                     k_chol_panel<<<below, 256, sizeof(PanelSmem), s>>>(A, ld, k0, X, info));
             // inner update: columns of this outer block to the right of the panel
             const int tj0 = k0 / TILE + 1, tj1 = K1 / TILE;
@@ -318,7 +318,7 @@ extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, vo
                 dim3 grid(tj1 - tj0, nt - tj0);
                 double tiles = 0;
                 for (int bj = tj0; bj < tj1; ++bj) tiles += nt - bj;
-                SLK_RUN("chol_syrk_inner", tiles * 2.0 * 64 * 64 * PANEL, 8.0 * (ld - k0) * PANEL + tiles * 16.0 * 64 * 64, s,
+                SLK_RUN_W("chol_syrk_inner", tiles * 2.0 * 64 * 64 * PANEL, 8.0 * (ld - k0) * PANEL + tiles * 16.0 * 64 * 64, tiles, s,
                         k_syrk_tiles<<<grid, 256, 0, s>>>(A, ld, tj0, tj0, k0, k0 + PANEL));
             }
         }
@@ -326,7 +326,7 @@ extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, vo
         if (nt > t0) {
             dim3 grid(nt - t0, nt - t0);
             const double tiles = 0.5 * (nt - t0) * (nt - t0 + 1);
-            SLK_RUN("chol_syrk_outer", tiles * 2.0 * 64 * 64 * (K1 - K0), 8.0 * (ld - K1) * (K1 - K0) + tiles * 16.0 * 64 * 64, s,
+            SLK_RUN_W("chol_syrk_outer", tiles * 2.0 * 64 * 64 * (K1 - K0), 8.0 * (ld - K1) * (K1 - K0) + tiles * 16.0 * 64 * 64, tiles, s,
                     k_syrk_tiles<<<grid, 256, 0, s>>>(A, ld, t0, t0, K0, K1));
         }
     }
@@ -344,8 +344,8 @@ extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, vo
                     tiles += 1;
                 }
         }
-        SLK_RUN("trtri_stage0", f0, f0 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64, s, k_trtri_level<0><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
-        SLK_RUN("trtri_stage1", f1, f1 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64, s, k_trtri_level<1><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
+        SLK_RUN_W("trtri_stage0", f0, f0 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64, tiles, s, k_trtri_level<0><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
+        SLK_RUN_W("trtri_stage1", f1, f1 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64, tiles, s, k_trtri_level<1><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
     }
     SLK_RUN("flip_out", 0, 12.0 * n * n, s, k_flip_out<<<n < 2048 ? n : 2048, 256, 0, s>>>(X, ld, n, U));
     return SLK_OK;

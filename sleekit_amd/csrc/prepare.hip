@@ -205,7 +205,7 @@ int slk_inverse_diag_keys(const double *U, const float *H, int n, float damp, in
         return SLK_E_WS;
     }
     hipStream_t s = as_stream(stream);
-    SLK_RUN("diag_mean", 0, 4.0 * n, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
+    SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
     SLK_RUN("order_keys", 0, 12.0 * n, s, k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, nullptr, scal, tmp));
     SLK_RUN("inverse_diag_keys", 0, 4.0 * n * n, s,
             k_inverse_diag_keys<<<(n + 255) / 256, 256, 0, s>>>(U, H, scal, n, combined, keys));
@@ -215,7 +215,7 @@ int slk_inverse_diag_keys(const double *U, const float *H, int n, float damp, in
 int slk_diag_mean(const float *H, int n, float *out, void *, size_t, slk_stream_t stream) {
     SLK_REQUIRE(H && out && n > 0, "bad arguments");
     hipStream_t s = as_stream(stream);
-    SLK_RUN("diag_mean", 0, 4.0 * n, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, out));
+    SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, out));
     return SLK_OK;
 }
 
@@ -236,7 +236,7 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
     }
     hipStream_t s = as_stream(stream);
     const int ld = slk_factor_ld(n);
-    SLK_RUN("diag_mean", 0, 4.0 * n, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
+    SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
     const bool weighted = order_mode == SLK_ORDER_ERR || order_mode == SLK_ORDER_SQERR;
     SLK_RUN("order_keys", 0, 12.0 * n, s,
             k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, weighted ? miss : nullptr, scal, keys));

@@ -21,8 +21,21 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
     __shared__ float rowpart[2][T32];
     // Column tiles are rotated by the row-tile index: with the symmetric shortcut below a tile's
     // depth grows with its column, and blocks id, id + 256, ... (same CU) must not all be deep.
-    const int tile_x = (blockIdx.x + blockIdx.y) % n_tiles;
-    const int r0 = blockIdx.y * T32, j0 = tile_x * T32;
+    // XCD-aware tile order.  Workgroup i runs on XCD i % 8; each XCD has its own L2.  XCD x takes a
+    // contiguous run of the row-major tile list (for a square 4096 layer: four row tiles by all
+    // 32 column tiles = its 128 resident workgroups), so its L2 holds 4 row panels of W - Q and one
+    // sweep of H instead of every XCD streaming every panel (2.8 GB past the L2 per launch before).
+    // Within a row the column is rotated with the row and mirrored on odd rows: with the symmetric
+    // shortcut below a tile's depth grows with its column, and the workgroups that share a CU
+    // (i, i + 256, ...) must not all be deep.
+    const int n_rt = (R + T32 - 1) / T32, n_all = n_tiles * n_rt;
+    const int per_xcd = (n_all + 7) / 8;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= n_all) return;
+    const int tile_y = lin / n_tiles, in_row = lin - tile_y * n_tiles;
+    const int rot = (in_row + tile_y * max(1, n_tiles / 4)) % n_tiles;
+    const int tile_x = (tile_y & 1) ? n_tiles - 1 - rot : rot;
+    const int r0 = tile_y * T32, j0 = tile_x * T32;
     const int t = threadIdx.x;
     Acc128 acc;
     acc.zero();
@@ -226,7 +239,8 @@ int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n,
         return SLK_E_WS;
     }
     hipStream_t s = as_stream(stream);
-    dim3 grid(n_tiles, (R + T32 - 1) / T32);
+    const int n_all = n_tiles * ((R + T32 - 1) / T32);
+    dim3 grid(8 * ((n_all + 7) / 8));  // a multiple of the 8 XCDs: see the tile order in the kernel
     const int vec_ok = n % 4 == 0 && ((uintptr_t)W | (uintptr_t)Q | (uintptr_t)H) % 16 == 0;
     const bool try_sym = G == nullptr && getenv("SLK_NO_SYM_ERROR") == nullptr;
     if (try_sym) {

@@ -225,6 +225,39 @@ def test_loop_blockings_match_oracle(amd, min_block, num_blocks):
     np.testing.assert_allclose(E1, E0, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("n", [96, 768, 1024, 1376, 3072, 4096])
+@pytest.mark.parametrize("odd_diagonal", [False, True])
+def test_window_kernels_agree(amd, n, odd_diagonal, monkeypatch):
+    """The standard-schedule window kernel (row-independent chain waves, 4x4x4 MFMA local updates,
+    helper waves) against the general one (16-row MFMA, barriers), bit for bit on Q and E: every
+    BASELINE width (one- and two-leaf periods, 32 + 16 and 5 x 32 + 12 leaves), a ragged last row
+    tile, and a diagonal entry with an all-ones significand (exact-division exception: true divides)."""
+    rng = np.random.default_rng(n)
+    R = 40
+    W = (rng.standard_normal((R, n)) * 0.6).astype(np.float32)
+    U = np.triu(rng.standard_normal((n, n)) * (0.3 / np.sqrt(n))) + np.diag(1.0 + rng.random(n))
+    if odd_diagonal:
+        U[n // 3, n // 3] = np.nextafter(2.0, 0.0)  # 1.111...1b: the fma division shortcut is not exact for it
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    out = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("SLK_NO_WINDOW2", "1")
+        else:
+            monkeypatch.delenv("SLK_NO_WINDOW2", raising=False)
+        Q, E = W.copy(), np.zeros_like(W)
+        amd.obq._quantize_opt_block(Q, E, U, cb, 32, 8)
+        out.append((Q, E))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    # and both against the oracle on the narrow cases (seconds on the CPU)
+    if n <= 1024:
+        Q0, E0 = W.copy(), np.zeros_like(W)
+        obq_ref.run_schedule(Q0, E0, U, grid.UniformGrid(8, -1, 1), obq_ref.block_schedule(n, 32, 8))
+        assert np.array_equal(out[0][0], Q0)
+        np.testing.assert_allclose(out[0][1], E0, rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("levels,lo,hi", [(2, -1, 1), (3, -1, 1), (4, -1, 1), (8, -1, 1), (16, -1, 1), (256, -1, 1), (5, -0.75, 1.25), (7, 0.0, 3.0)])
 def test_fast_quantizer_matches_true_divide(amd, levels, lo, hi):
     """The leaf kernel replaces the float32 divide by an exact-division fma sequence; with an

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                                                       Grid g, float inv_step, int fast_ok, int prof, PeriodTable tab) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Window2Smem &sm = *reinterpret_cast<Window2Smem *>(smem_raw);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // readfirstlane: tells the compiler the wave index is wave-uniform (scalar branches, SGPR addressing)
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     // cycle accounting (debug, SLK_WIN_DBG bit 3): wave-uniform, workgroup 0, waves 0 and 4
     const bool timing = (prof & 8) && blockIdx.x == 0;
     long long tmark = timing ? (long long)__builtin_readcyclecounter() : 0;
@@ -114,10 +115,32 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
     const int width = w1 - w0;
     auto ring = [&](int c) { return (c - w0) & (ERING - 1); };
 
-    // columns [c_lo, c_hi) of the Q tile, global -> LDS, by `nth` threads of which this is number `tid`;
-    // eight loads in flight per thread (a load-wait-store loop pays the full latency per element)
+    // columns [c_lo, c_hi) of the Q tile, global -> LDS, by `nth` threads of which this is number `tid`:
+    // 16-byte loads when the layout allows, eight (four) loads in flight per thread either way
+    // (a load-wait-store loop pays the full latency per element)
+    const bool vec4 = n % 4 == 0 && (w0 & 3) == 0 && ((uintptr_t)Qp & 15) == 0;
     auto load_cols = [&](int c_lo, int c_hi, int tid, int nth) {
-        const int cw = c_hi - c_lo, total = RB * cw;
+        const int cw = c_hi - c_lo;
+        if (vec4 && (c_lo & 3) == 0 && (cw & 3) == 0) {
+            const int cw4 = cw >> 2, total = RB * cw4;
+            for (int e0 = tid; e0 < total; e0 += 4 * nth) {
+                float4v_t v[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int e = min(e0 + h * nth, total - 1);
+                    const int r = e / cw4, c = c_lo + 4 * (e % cw4);
+                    v[h] = *reinterpret_cast<const float4v_t *>(Qp + (size_t)min(r0 + r, R - 1) * n + c);
+                }
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int e = e0 + h * nth;
+                    const int r = e / cw4, c = c_lo + 4 * (e % cw4);
+                    if (e < total) *reinterpret_cast<float4v_t *>(&sm.q[r][c - w0]) = (r0 + r < R) ? v[h] : (float4v_t){0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
+            return;
+        }
+        const int total = RB * cw;
         for (int e0 = tid; e0 < total; e0 += 8 * nth) {
             float v[8];
 #pragma unroll
@@ -311,6 +334,8 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
         // ---- the 16-row MFMA update of v1 on four waves: Q[:, lo:hi] -= E[:, a:b] @ U[a:b, lo:hi]
         const int lr = lane & 15, lk = lane >> 4;
         double cur[16];
+        // (Scalar per-row-group bases with one vector offset were tried to take the address arithmetic
+        // off the vector ALU, which the float64 MFMA shares: the SALU chain it needs is slower, 36 vs 31 us.)
         auto load_round = [&](int a, int b, int lo, int hi, int blk, int kc, double(&bv)[16]) {
             const int cc = min(lo + blk * 16 + lr, hi - 1);
 #pragma unroll
@@ -440,9 +465,17 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
     }
 
     // every column is final: the tile goes back (E went out leaf by leaf)
-    for (int e = t; e < RB * width; e += 512) {
-        const int r = e / width, c = e % width;
-        if (r0 + r < R) Qp[(size_t)(r0 + r) * n + w0 + c] = sm.q[r][c];
+    if (vec4 && (width & 3) == 0) {
+        const int cw4 = width >> 2;
+        for (int e = t; e < RB * cw4; e += 512) {
+            const int r = e / cw4, c = 4 * (e % cw4);
+            if (r0 + r < R) *reinterpret_cast<float4v_t *>(Qp + (size_t)(r0 + r) * n + w0 + c) = *reinterpret_cast<const float4v_t *>(&sm.q[r][c]);
+        }
+    } else {
+        for (int e = t; e < RB * width; e += 512) {
+            const int r = e / width, c = e % width;
+            if (r0 + r < R) Qp[(size_t)(r0 + r) * n + w0 + c] = sm.q[r][c];
+        }
     }
     if (timing && lane == 0 && (wave == 0 || wave == 2)) {
 #pragma unroll

@@ -105,6 +105,11 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
  * (combined == 0, "inv_diag") or -diag(Hd)[j] / diag(Hd^-1)[j] (combined != 0, "combined_diag").  */
 int slk_inverse_diag_keys(const double *U, const float *H, int n, float damp, int combined, double *keys,
                           void *workspace, size_t ws_bytes, slk_stream_t stream);
+/* Sort keys of the "pivot" order (greedy pivoted Cholesky, sleekit/obq.py:78, 140-166): keys[j] = the
+ * step at which column j of Hd = float64(H) + float32(damp * mean(diag H)) * I is picked.  A cold path:
+ * 2 n small launches, n^3 / 6 divide-subtract terms; needs 8 n^2 + O(n) bytes of workspace.          */
+int slk_pivot_keys(const float *H, int n, float damp, double *keys, void *workspace, size_t ws_bytes,
+                   slk_stream_t stream);
 /* Leading dimension (and row count) of the padded float64 matrices A / scratch. */
 int slk_factor_ld(int n);
 /* Same layout from a float64 matrix as is (no damping, no order): A = reversed lower

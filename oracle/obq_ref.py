@@ -7,7 +7,8 @@ Restates the hot path of the reference `sleekit/obq.py`:
     strip_input_mean      obq.py:14-25    (remove_input_bias)
     patch_dead_columns    obq.py:28-35    (remove_dead_values)
     inverse_factor_upper  obq.py:38-55    (compute_hessian_chol)
-    column_order          obq.py:58-86    (compute_hessian_order; all modes but pivot)
+    column_order          obq.py:58-86    (compute_hessian_order)
+    pivot_order           obq.py:140-166  (_cholesky_ordering, without forming the trailing matrix)
     row_errors/mean_error obq.py:89-103   (channelwise_error/quantization_error)
     block_schedule        obq.py:121-137  (the recursion of _quantize_opt_block, flattened)
     run_schedule          obq.py:106-137  (_quantize_opt_core + block updates)
@@ -88,7 +89,39 @@ def column_order(W, H, grid, mode, ties="numpy"):
         return (-H.diagonal() / np.linalg.inv(H).diagonal()).argsort(kind=kind)
     if mode == "inv_diag":  # obq.py:73-75
         return np.linalg.inv(H).diagonal().argsort(kind=kind)
+    if mode == "pivot":  # obq.py:76-78
+        return pivot_order(H)
     raise RuntimeError(f"Invalid act_order value {mode}")
+
+
+def pivot_order(H):
+    """Greedy pivoted-Cholesky order (obq.py:140-166), restated without the trailing matrix.
+
+    The reference swaps rows/columns of a full copy and applies `L[k+1:, k+1:] -= outer(b, b) / L[k, k]`
+    at every step.  Only the order is wanted, so this restatement keeps the pivot rows b_m and the
+    diagonal, and evaluates row p_k of the trailing matrix when column p_k is picked:
+        M_k[p_k][v] = H[p_k][v] - sum_{m<k} (b_m[p_k] * b_m[v]) / d_m
+    term by term in step order, each with the reference's three roundings (product, quotient,
+    difference).  Ties in |diagonal| go to the first POSITION, positions following the reference's swaps.
+    """
+    H = np.asarray(H, dtype=np.float64)
+    n = H.shape[0]
+    pos = np.arange(n)          # column held by each position (the reference's `order`)
+    diag = H.diagonal().copy()
+    B = np.zeros((n, n))        # B[m, v] = b_m[v] for the columns v still free at step m
+    d = np.zeros(n)
+    for k in range(n):
+        j = int(np.argmax(np.abs(diag[pos[k:]]))) + k
+        pos[[k, j]] = pos[[j, k]]
+        p = pos[k]
+        d[k] = diag[p]
+        rest = pos[k + 1 :]
+        x = H[p, rest].copy()
+        for m in range(k):
+            x = x - (B[m, p] * B[m, rest]) / d[m]
+        B[k, rest] = x
+        diag[rest] = diag[rest] - (x * x) / d[k]
+    return pos
 
 
 # --------------------------------------------------------------------------

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "slk_column_miss": (c_int, [P, c_int, c_int, c_int, c_double, c_double, c_int, P, P]),
     "slk_hessian_prepare": (c_int, [P, c_int, c_float, c_int, P, P, P, P, c_size_t, P]),
     "slk_inverse_diag_keys": (c_int, [P, P, c_int, c_float, c_int, P, P, c_size_t, P]),
+    "slk_pivot_keys": (c_int, [P, c_int, c_float, P, P, c_size_t, P]),
     "slk_factor_ld": (c_int, [c_int]),
     "slk_factor_load": (c_int, [P, c_int, P, P]),
     "slk_chol_inverse_upper": (c_int, [P, c_int, P, P, P, c_size_t, P]),

@@ -581,17 +581,17 @@ __global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, c
     if (vec_ok && r0 + TILE <= R && j0 + TILE <= jb && kend == kb) {
         const float *pe = Eg + (size_t)a_row * n + a_k;
         const double *pu = U + (size_t)b_k * n + b_col;
-        tile64_mac<true>(
-            acc, sm, ka, kend, [&](int k0, double(&v)[8]) { load8f_as_d<true>(pe + k0, v); },
+        tile64_mac<true, float>(
+            acc, sm, ka, kend, [&](int k0, float(&v)[8]) { load8f<true>(pe + k0, v); },
             [&](int k0, double(&v)[8]) { load8d<true>(pu + (size_t)k0 * n, v); });
     } else {
         const bool row_ok = a_row < R;
         const float *pe = Eg + (size_t)min(a_row, R - 1) * n;
-        tile64_mac<true>(
+        tile64_mac<true, float>(
             acc, sm, ka, kend,
-            [&](int k0, double(&v)[8]) {
+            [&](int k0, float(&v)[8]) {
                 const int k = k0 + a_k;
-                load8f_as_d_guarded(pe + min(k, kb - 1), kb - 1 - k, row_ok, v);
+                load8f_guarded(pe + min(k, kb - 1), kb - 1 - k, row_ok, v);
             },
             [&](int k0, double(&v)[8]) {
                 const int k = k0 + b_k;

@@ -88,25 +88,48 @@ __device__ __forceinline__ void load8f_as_d(const float *p, double (&v)[8]) {
         for (int e = 0; e < 8; ++e) v[e] = (double)p[e];
     }
 }
+// 8 consecutive floats, kept as floats.
+template <bool VEC>
+__device__ __forceinline__ void load8f(const float *p, float (&v)[8]) {
+    if (VEC) {
+        const float4v_t lo = *reinterpret_cast<const float4v_t *>(p), hi = *reinterpret_cast<const float4v_t *>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = lo[e];
+            v[4 + e] = hi[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p[e];
+    }
+}
+__device__ __forceinline__ void load8f_guarded(const float *p, int last, bool ok, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = p[min(e, max(last, 0))] * ((ok && e <= last) ? 1.0f : 0.0f);
+}
 __device__ __forceinline__ void load8f_as_d_guarded(const float *p, int last, bool ok, double (&v)[8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (double)p[min(e, max(last, 0))] * ((ok && e <= last) ? 1.0 : 0.0);
 }
 
 // acc += A(64 x K) * B(K x 64) for k in [k_begin, k_end), k_end - k_begin a multiple of KSTEP.
-template <bool B_C_FAST, class LA, class LB>
+// TA: type of the A fragment held in registers between its global load and the LDS write (double, or
+// float for a float32 operand: the widening then happens at the LDS write, a whole MFMA phase after the
+// load was issued -- converted at once it would make the wave wait for the load before its MFMAs).
+template <bool B_C_FAST, class TA = double, class LA, class LB>
 __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_begin, int k_end, LA la, LB lb) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    double ra[8], rb[8];
+    TA ra[8];
+    double rb[8];
     double *a_dst = sm.a + (t >> 2) * PITCH_RK + (t & 3) * 8;
     double *b_dst = B_C_FAST ? sm.b + (t >> 3) * PITCH_KC + (t & 7) * 8 : sm.b + (t >> 2) * PITCH_RK + (t & 3) * 8;
 
     auto stash = [&]() {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            *reinterpret_cast<double2_t *>(a_dst + 2 * h) = (double2_t){ra[2 * h], ra[2 * h + 1]};
+            *reinterpret_cast<double2_t *>(a_dst + 2 * h) = (double2_t){(double)ra[2 * h], (double)ra[2 * h + 1]};
             *reinterpret_cast<double2_t *>(b_dst + 2 * h) = (double2_t){rb[2 * h], rb[2 * h + 1]};
         }
     };
@@ -117,6 +140,16 @@ __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_beg
     const double *a_src = sm.a + (wr * 32 + (lane & 15)) * PITCH_RK + (lane >> 4);
     const double *b_src = B_C_FAST ? sm.b + (lane >> 4) * PITCH_KC + wc * 32 + (lane & 15)
                                    : sm.b + (wc * 32 + (lane & 15)) * PITCH_RK + (lane >> 4);
+    // The second operand of each pair gets a base of its own that the compiler cannot relate to the
+    // first: left to itself it fuses the pair into ds_read2_b64, which runs at HALF the rate of two
+    // ds_read_b64 and banks modulo 32 over 16-lane groups -- 2-way conflicts on these images, laid
+    // out for ds_read_b64 (32-lane halves, 64 banks).  Measured: 46 % of the LDS cycles were conflicts.
+    // (the distance goes through an opaque register; laundering the pointer itself would lose the
+    // LDS address space and turn the reads into flat loads)
+    int a_off1 = 16 * PITCH_RK, b_off1 = B_C_FAST ? 16 : 16 * PITCH_RK;
+    asm volatile("" : "+v"(a_off1), "+v"(b_off1));
+    const double *a_src1 = a_src + a_off1;
+    const double *b_src1 = b_src + b_off1;
     for (int k0 = k_begin; k0 < k_end; k0 += KSTEP) {
         __syncthreads();  // previous step's LDS reads are done
         stash();
@@ -125,11 +158,19 @@ __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_beg
             la(k0 + KSTEP, ra);
             lb(k0 + KSTEP, rb);
         }
+        // operands of group kk + 4 are read from LDS before the MFMAs of group kk are issued
+        double a0n = a_src[0], a1n = a_src1[0];
+        double b0n = b_src[0], b1n = b_src1[0];
 #pragma unroll
         for (int kk = 0; kk < KSTEP; kk += 4) {
-            const double a0 = a_src[kk], a1 = a_src[16 * PITCH_RK + kk];
-            const double b0 = B_C_FAST ? b_src[kk * PITCH_KC] : b_src[kk];
-            const double b1 = B_C_FAST ? b_src[kk * PITCH_KC + 16] : b_src[16 * PITCH_RK + kk];
+            const double a0 = a0n, a1 = a1n, b0 = b0n, b1 = b1n;
+            if (kk + 4 < KSTEP) {
+                a0n = a_src[kk + 4];
+                a1n = a_src1[kk + 4];
+                b0n = B_C_FAST ? b_src[(kk + 4) * PITCH_KC] : b_src[kk + 4];
+                b1n = B_C_FAST ? b_src1[(kk + 4) * PITCH_KC] : b_src1[kk + 4];
+            }
+            asm volatile("" : "+v"(acc.c[0][0]), "+v"(acc.c[0][1])::"memory");  // keep the reads above the MFMAs
             acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.c[0][0], 0, 0, 0);
             acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.c[0][1], 0, 0, 0);
             acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.c[1][0], 0, 0, 0);

@@ -145,6 +145,81 @@ __global__ __launch_bounds__(256) void k_unpack_factor(const long long *__restri
     }
 }
 
+// ------------------------------------------------------------------ "pivot" order (obq.py:140-166)
+// Greedy pivoted Cholesky of the damped Hessian: at step k the remaining column with the largest
+// |conditional variance| (first one in the current POSITION order on ties: positions change with the
+// reference's swaps) becomes column k.  Only the order is wanted, so the trailing matrix is never
+// formed: row p_k of it is evaluated lazily,
+//     M_k[p_k][v] = Hd[p_k][v] - sum_{m<k} (b_m[p_k] * b_m[v]) / d_m      (b_m = pivot row of step m)
+// with the reference's three roundings per term (product, quotient, difference) in the order of its
+// in-place update, and the diagonal is carried along the same way.  n steps of two small launches:
+// n^3 / 6 divide-subtract terms on at most (n - k) lanes -- a cold path (no BASELINE config uses it).
+__global__ __launch_bounds__(256) void k_pivot_init(const float *__restrict__ H, int n, const float *__restrict__ scal,
+                                                    double *__restrict__ diag, int *__restrict__ pos) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    diag[v] = (double)H[(size_t)v * n + v] + (double)scal[1];
+    pos[v] = v;
+}
+
+// one workgroup: first maximum of |diag| over positions k .. n-1, swapped into position k
+__global__ __launch_bounds__(256) void k_pivot_select(const double *__restrict__ diag, int *__restrict__ pos, int n, int k,
+                                                      int *__restrict__ piv, double *__restrict__ dpiv) {
+    __shared__ double bv[256];
+    __shared__ int bj[256];
+    double best = -1.0;
+    int at = n;
+    for (int j = k + threadIdx.x; j < n; j += 256) {
+        const double a = fabs(diag[pos[j]]);
+        if (a > best || !(best >= 0.0)) {  // strict: keeps the first; a NaN never wins over a number
+            if (a == a) best = a, at = j;
+        }
+    }
+    bv[threadIdx.x] = best;
+    bj[threadIdx.x] = at;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (threadIdx.x < w) {
+            const double o = bv[threadIdx.x + w];
+            const int oj = bj[threadIdx.x + w];
+            if (o > bv[threadIdx.x] || (o == bv[threadIdx.x] && oj < bj[threadIdx.x])) bv[threadIdx.x] = o, bj[threadIdx.x] = oj;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int j = bj[0] < n ? bj[0] : k;  // all NaN: keep the position
+        const int p = pos[j];
+        pos[j] = pos[k];
+        pos[k] = p;
+        piv[k] = p;
+        dpiv[k] = diag[p];
+    }
+}
+
+// row p_k of the trailing matrix for every remaining column, and the diagonal update of this step
+__global__ __launch_bounds__(256) void k_pivot_row(const float *__restrict__ H, int n, const float *__restrict__ scal,
+                                                   const int *__restrict__ pos, const int *__restrict__ piv,
+                                                   const double *__restrict__ dpiv, int k, double *__restrict__ B,
+                                                   double *__restrict__ diag) {
+    const int j = k + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int v = pos[j], p = piv[k];
+    double x = (double)H[(size_t)p * n + v] + (p == v ? (double)scal[1] : 0.0);
+    for (int m = 0; m < k; ++m) {
+        const double prod = B[(size_t)m * n + p] * B[(size_t)m * n + v];
+        x = x - prod / dpiv[m];
+    }
+    B[(size_t)k * n + v] = x;
+    const double sq = x * x;
+    diag[v] = diag[v] - sq / dpiv[k];
+}
+
+// keys[piv[k]] = k: sorting them ascending (slk_hessian_prepare, SLK_ORDER_KEYS) gives the pivot order
+__global__ __launch_bounds__(256) void k_pivot_keys(const int *__restrict__ piv, int n, double *__restrict__ keys) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) keys[piv[k]] = (double)k;
+}
+
 }  // namespace slk
 
 using namespace slk;
@@ -209,6 +284,36 @@ int slk_inverse_diag_keys(const double *U, const float *H, int n, float damp, in
     SLK_RUN("order_keys", 0, 12.0 * n, s, k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, nullptr, scal, tmp));
     SLK_RUN("inverse_diag_keys", 0, 4.0 * n * n, s,
             k_inverse_diag_keys<<<(n + 255) / 256, 256, 0, s>>>(U, H, scal, n, combined, keys));
+    return SLK_OK;
+}
+
+int slk_pivot_keys(const float *H, int n, float damp, double *keys, void *workspace, size_t ws_bytes,
+                              slk_stream_t stream) {
+    SLK_REQUIRE(H && keys && n > 0, "bad arguments");
+    Arena ws(workspace, ws_bytes);
+    float *scal = ws.take<float>(64);
+    double *tmp = ws.take<double>((size_t)n);
+    double *diag = ws.take<double>((size_t)n);
+    double *dpiv = ws.take<double>((size_t)n);
+    int *pos = ws.take<int>((size_t)n);
+    int *piv = ws.take<int>((size_t)n);
+    double *B = ws.take<double>((size_t)n * n);
+    if (!scal || !tmp || !diag || !dpiv || !pos || !piv || !B) {
+        set_error("workspace too small for the pivot order of a %d-column Hessian", n);
+        return SLK_E_WS;
+    }
+    hipStream_t s = as_stream(stream);
+    const int nb = (n + 255) / 256;
+    SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
+    SLK_RUN("order_keys", 0, 12.0 * n, s, k_order_keys<<<nb, 256, 0, s>>>(H, n, damp, nullptr, scal, tmp));  // scal[1] = damping term
+    SLK_RUN("pivot_init", 0, 16.0 * n, s, k_pivot_init<<<nb, 256, 0, s>>>(H, n, scal, diag, pos));
+    for (int k = 0; k < n; ++k) {
+        SLK_RUN_W("pivot_select", 0, 12.0 * (n - k), 1, s, k_pivot_select<<<1, 256, 0, s>>>(diag, pos, n, k, piv, dpiv));
+        if (k + 1 < n)
+            SLK_RUN_W("pivot_row", 3.0 * k * (n - k - 1), 16.0 * k * (n - k - 1), (n - k - 1 + 255) / 256, s,
+                      k_pivot_row<<<(n - k - 1 + 255) / 256, 256, 0, s>>>(H, n, scal, pos, piv, dpiv, k, B, diag));
+    }
+    SLK_RUN("pivot_keys", 0, 12.0 * n, s, k_pivot_keys<<<nb, 256, 0, s>>>(piv, n, keys));
     return SLK_OK;
 }
 

@@ -16,19 +16,15 @@ from . import _device as dev
 from . import _lib
 from .codebook import UniformCodebook
 
-_UNSUPPORTED_ORDERS = ("pivot",)
 _INVERSE_ORDERS = {"inv_diag": 0, "combined_diag": 1}  # need diag(Hd^-1): two factorisations
+_KEY_ORDERS = ("inv_diag", "combined_diag", "pivot")     # sort keys computed by a kernel of their own
 
 
 def order_mode_code(act_order):
     if act_order in _lib.ORDER_MODES:
         return _lib.ORDER_MODES[act_order]
-    if act_order in _INVERSE_ORDERS:
+    if act_order in _KEY_ORDERS:
         return _lib.ORDER_KEYS
-    if act_order in _UNSUPPORTED_ORDERS:
-        raise NotImplementedError(
-            f"act_order={act_order!r} (greedy pivoted Cholesky, obq.py:140-166) is outside the accelerated path"
-        )
     raise RuntimeError(f"Invalid act_order value {act_order}")
 
 
@@ -44,6 +40,21 @@ def inverse_diag_keys(H, n, damp, combined):
         )
     )
     return keys
+
+
+def pivot_keys(H, n, damp):
+    """Sort keys of the greedy pivoted-Cholesky order (obq.py:78, 140-166): the step at which each column is picked."""
+    ws, ws_bytes = dev.workspace(0, n)
+    keys = torch.empty(n, dtype=torch.float64, device=H.device)
+    _lib.check(_lib.lib.slk_pivot_keys(dev.ptr(H), n, float(damp), dev.ptr(keys), dev.ptr(ws), ws_bytes, dev.stream_handle()))
+    return keys
+
+
+def order_keys(H, n, damp, act_order):
+    """Keys of the orders that are not a function of the damped diagonal and the column statistics alone."""
+    if act_order == "pivot":
+        return pivot_keys(H, n, damp)
+    return inverse_diag_keys(H, n, damp, _INVERSE_ORDERS[act_order])
 
 
 def require_uniform(quantizer):
@@ -188,7 +199,7 @@ def quantize_layer(
 
     if factor is None:
         if mode == _lib.ORDER_KEYS:
-            miss = inverse_diag_keys(H, n, damp, _INVERSE_ORDERS[act_order])
+            miss = order_keys(H, n, damp, act_order)
         else:
             miss = column_miss(Ws, cb_abi, mode == _lib.ORDER_SQERR) if mode >= _lib.ORDER_ERR else None
         factor = factorize(H, n, damp, mode, miss)

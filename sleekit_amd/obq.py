@@ -84,7 +84,7 @@ def compute_hessian_order(W, H, quantizer, act_order):
     Wd, Hd = dev.to_device(W), dev.to_device(H)
     miss = None
     if mode == _lib.ORDER_KEYS:
-        miss = engine.inverse_diag_keys(Hd, n, 0.0, engine._INVERSE_ORDERS[act_order])
+        miss = engine.order_keys(Hd, n, 0.0, act_order)
     elif mode >= _lib.ORDER_ERR:
         miss = engine.column_miss(Wd, engine.require_uniform(quantizer), mode == _lib.ORDER_SQERR)
     # damp = 0: the caller's H already carries its damping

@@ -123,6 +123,12 @@ def pieces():
     for k in ("value", "index", "up", "down"):
         P[f"cb/asym/{k}"] = getattr(cb, "quantize_" + k)(x)
 
+    # --- greedy pivoted-Cholesky order (obq.py:140-166) on damped float64 Hessians ---
+    for tag, (R_, n_, seed_) in (("96", (64, 96, 2001)), ("256", (32, 256, 2050))):
+        Lp = synth.make_layer(R_, n_, seed_)
+        Hd = Lp["H"].astype(np.float32) + np.float32(0.01 * Lp["H"].astype(np.float32).diagonal().mean()) * np.eye(n_)
+        P[f"pivot/{tag}/order"] = ref_obq.compute_hessian_order(Lp["W"], Hd, UniformCodebook(8, -1, 1), "pivot").astype(np.int64)
+
     # --- Hessian preparation + factor + full debug trace on one tiny layer ---
     L = synth.make_layer(8, 16, 2000)
     W, H = L["W"].copy(), L["H"].copy()

@@ -327,8 +327,27 @@ def test_orders_from_the_inverse_diagonal(amd, order):
         want = scaling_ref.quantize_scaled(L["W"], L["scale"], g, L["H"], order, 0.01, 0)
         got = amd.scaling.quantize_with_scaling(L["W"], L["scale"], cb, L["H"], act_order=order, damp=0.01)
         assert np.array_equal(got, want), (order, n)
-    with pytest.raises(NotImplementedError):
-        amd.obq.quantize_opt(L["W"], L["H"], cb, act_order="pivot")
+
+
+def test_pivot_order(amd, pieces):
+    """obq.py:140-166: greedy pivoted Cholesky.  The order against the reference's own (fixture), then a
+    layer quantized in that order against the oracle."""
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    for tag, (R, n, seed) in (("96", (64, 96, 2001)), ("256", (32, 256, 2050))):
+        L = layer(R, n, seed)
+        H32 = L["H"].astype(np.float32)
+        Hd = H32 + np.float32(0.01 * H32.diagonal().mean()) * np.eye(n)
+        got = amd.obq.compute_hessian_order(L["W"], Hd.astype(np.float32), cb, "pivot")
+        # the damped float64 matrix rounded to float32 is not the reference's input: the device API damps itself
+        import torch
+        keys = amd.engine.pivot_keys(torch.as_tensor(H32, device="cuda"), n, 0.01)
+        order = torch.argsort(keys).cpu().numpy()
+        assert np.array_equal(order, pieces[f"pivot/{tag}/order"]), tag
+        assert sorted(got.tolist()) == list(range(n))
+        g = grid.UniformGrid(8, -1, 1)
+        want = scaling_ref.quantize_scaled(L["W"], L["scale"], g, L["H"], "pivot", 0.01, 0)
+        out = amd.scaling.quantize_with_scaling(L["W"], L["scale"], cb, L["H"], act_order="pivot", damp=0.01)
+        assert np.array_equal(out, want), tag
 
 
 def test_local_search_standalone(amd):

@@ -147,6 +147,15 @@ def test_inverse_diagonal_orders_match_reference():
         assert np.array_equal(obq_ref.column_order(L["W"], Hd, None, mode), want)
 
 
+def test_pivot_order_matches_reference(pieces):
+    """obq.py:140-166: the greedy pivoted-Cholesky order, restated without the trailing matrix."""
+    for tag, (R, n, seed) in (("96", (64, 96, 2001)), ("256", (32, 256, 2050))):
+        L = layer(R, n, seed)
+        Hd = L["H"].astype(np.float32) + np.float32(0.01 * L["H"].astype(np.float32).diagonal().mean()) * np.eye(n)
+        assert np.array_equal(obq_ref.pivot_order(Hd), pieces[f"pivot/{tag}/order"])
+        assert np.array_equal(obq_ref.column_order(L["W"], Hd, None, "pivot"), pieces[f"pivot/{tag}/order"])
+
+
 def test_running_stats(pieces):
     X = pieces["stats/X"]
     st = stats_ref.RunningStats(48)

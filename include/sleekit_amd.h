@@ -36,7 +36,12 @@ extern "C" {
 #define SLK_E_HIP (-3)    /* a HIP runtime call or kernel launch failed              */
 #define SLK_E_WS (-4)     /* workspace too small                                     */
 
-/* codebook maps, slk_codebook_apply `what` */
+/* Codebooks.  Every entry point that quantizes takes (levels, lo, hi, table):
+ *   table == NULL  UniformCodebook(levels, lo, hi)            (sleekit/codebook.py:4-95)
+ *   table != NULL  general Codebook of `levels` <= 256 entries (sleekit/codebook.py:98-190): a DEVICE array of
+ *                  `levels` increasing float32 values followed by the `levels - 1` bin limits; the index of x
+ *                  is np.digitize(x, limits); lo / hi are ignored.
+ * codebook maps, slk_codebook_apply `what` */
 #define SLK_CB_VALUE 0 /* float32 out */
 #define SLK_CB_INDEX 1 /* uint8 out (levels <= 256) */
 #define SLK_CB_UP 2    /* float32 out */
@@ -58,10 +63,10 @@ const char *slk_last_error(void);
 /* Scratch bytes that any call below may use for an (R, n) layer. */
 size_t slk_workspace_bytes(int R, int n);
 
-/* a7  UniformCodebook.quantize_value/index/up/down  (sleekit/codebook.py:43-95)
+/* a7  UniformCodebook / Codebook .quantize_value/index/up/down  (sleekit/codebook.py:43-95, 150-190)
  *     out[i] = map(x[i]); float32 arithmetic, IEEE divide, round-half-even.    */
-int slk_codebook_apply(const float *x, size_t count, int levels, double lo, double hi, int what,
-                       void *out, slk_stream_t stream);
+int slk_codebook_apply(const float *x, size_t count, int levels, double lo, double hi, const float *table,
+                       int what, void *out, slk_stream_t stream);
 
 /* a14 apply_scaling on axis 0  (sleekit/scaling.py:21-25, 73, 80)
  *     invert == 0: out[r][j] = x[r][j] / scale[r]
@@ -88,8 +93,8 @@ int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T,
 
 /* a4  column statistics for the err / sqerr orders  (sleekit/obq.py:60-69)
  *     miss[j] = sum over rows, in row order, of |q(W) - W| (squared == 0) or its square. */
-int slk_column_miss(const float *W, int R, int n, int levels, double lo, double hi, int squared,
-                    float *miss, slk_stream_t stream);
+int slk_column_miss(const float *W, int R, int n, int levels, double lo, double hi, const float *table,
+                    int squared, float *miss, slk_stream_t stream);
 
 /* a3+a4+a5  damping, ordering, permutation  (sleekit/obq.py:198-204)
  *     Hd = float64(H) + float32(damp * mean(diag H)) * I
@@ -144,8 +149,8 @@ int slk_factor_unpack(const void *payload, int n, double *U, long long *order, i
  *     idx (may be NULL): codebook indices, uint8, original column order.
  *     E_out (may be NULL): the scaled errors E of obq.py:115, R x n, in PROCESSING order. */
 int slk_gptq_quantize(const float *W, const float *scale, const long long *order, const double *U,
-                      int R, int n, int levels, double lo, double hi, int min_block, int num_blocks,
-                      float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
+                      int R, int n, int levels, double lo, double hi, const float *table, int min_block,
+                      int num_blocks, float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
                       slk_stream_t stream);
 
 /* a11 channelwise_error  (sleekit/obq.py:89-95): row_err[r] = (W-Q)[r] H (W-Q)[r]^T.
@@ -158,7 +163,7 @@ int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n,
  *     (may be NULL) receives the indices of the result.  `moves` best-first
  *     single-weight moves per row.                                             */
 int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
-                     double hi, int moves, uint8_t *idx, void *workspace, size_t ws_bytes,
+                     double hi, const float *table, int moves, uint8_t *idx, void *workspace, size_t ws_bytes,
                      slk_stream_t stream);
 
 /* Scale selection: the callers' pre-step -------------------------- */
@@ -174,8 +179,8 @@ int slk_scale_norm(const float *W, int R, int n, float *scale, slk_stream_t stre
  * f * base[r], take the error sum_j [hdiag_j] E_j^2 in NumPy's summation order, keep the first
  * minimum; out[r] = base[r] * best factor.                                                   */
 int slk_scale_search(const float *W, const float *base, const float *factors, int n_factors,
-                     const float *hdiag, int R, int n, int levels, double lo, double hi, float *out,
-                     slk_stream_t stream);
+                     const float *hdiag, int R, int n, int levels, double lo, double hi, const float *table,
+                     float *out, slk_stream_t stream);
 /* Book-keeping of the searches whose row errors come from slk_row_errors (full Hessian, OBQ-aware;
  * sleekit/scaling.py:131-133, 187-189): init != 0 resets best_err / best_f to +inf; err != NULL
  * applies `better = err < best_err`.                                                          */

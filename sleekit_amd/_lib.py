@@ -32,12 +32,12 @@ PROTOTYPES = {
     "slk_abi_version": (c_int, []),
     "slk_last_error": (c_char_p, []),
     "slk_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "slk_codebook_apply": (c_int, [P, c_size_t, c_int, c_double, c_double, c_int, P, P]),
+    "slk_codebook_apply": (c_int, [P, c_size_t, c_int, c_double, c_double, P, c_int, P, P]),
     "slk_rows_divide": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "slk_hessian_strip_mean": (c_int, [P, P, c_int, P, P]),
     "slk_hessian_patch_dead": (c_int, [P, P, c_int, c_int, P, c_size_t, P]),
     "slk_hessian_accumulate": (c_int, [P, P, P, c_int, c_int, c_longlong, P]),
-    "slk_column_miss": (c_int, [P, c_int, c_int, c_int, c_double, c_double, c_int, P, P]),
+    "slk_column_miss": (c_int, [P, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P]),
     "slk_hessian_prepare": (c_int, [P, c_int, c_float, c_int, P, P, P, P, c_size_t, P]),
     "slk_inverse_diag_keys": (c_int, [P, P, c_int, c_float, c_int, P, P, c_size_t, P]),
     "slk_pivot_keys": (c_int, [P, c_int, c_float, P, P, c_size_t, P]),
@@ -49,13 +49,13 @@ PROTOTYPES = {
     "slk_factor_unpack": (c_int, [P, c_int, P, P, P, P]),
     "slk_gptq_quantize": (
         c_int,
-        [P, P, P, P, c_int, c_int, c_int, c_double, c_double, c_int, c_int, P, P, P, P, c_size_t, P],
+        [P, P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, c_int, P, P, P, P, c_size_t, P],
     ),
     "slk_row_errors": (c_int, [P, P, P, c_int, c_int, P, P, P, c_size_t, P]),
-    "slk_local_search": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_double, c_int, P, P, c_size_t, P]),
+    "slk_local_search": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P, c_size_t, P]),
     "slk_scale_minmax": (c_int, [P, c_int, c_int, c_double, c_double, P, P]),
     "slk_scale_norm": (c_int, [P, c_int, c_int, P, P]),
-    "slk_scale_search": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_double, c_double, P, P]),
+    "slk_scale_search": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_double, c_double, P, P, P]),
     "slk_search_step": (c_int, [P, c_float, c_int, P, P, c_int, P]),
     "slk_scale_times": (c_int, [P, P, c_float, c_int, P, P]),
     "slk_diag_mean": (c_int, [P, c_int, P, P, c_size_t, P]),

@@ -82,17 +82,23 @@ struct Arena {
     }
 };
 
-// Uniform codebook in float32, formed exactly like the reference
-// (sleekit/codebook.py:35-41 under NEP 50: the Python-float step is cast to float32).
+// Codebook in float32.  Uniform (table == nullptr): formed exactly like the reference
+// (sleekit/codebook.py:35-41 under NEP 50: the Python-float step is cast to float32).  General
+// (sleekit/codebook.py:98-190): `table` points to n sorted values followed by the n - 1 bin limits;
+// a value's index is np.digitize(x, limits) = the number of limits <= x.
 struct Grid {
     float zero, step, top;  // top = levels - 1
+    const float *table;
+    int n;
 };
 
-static inline Grid make_grid(int levels, double lo, double hi) {
+static inline Grid make_grid(int levels, double lo, double hi, const float *table = nullptr) {
     Grid g;
     g.zero = (float)lo;
     g.step = (float)((hi - lo) / (double)(levels - 1));
     g.top = (float)(levels - 1);
+    g.table = table;
+    g.n = levels;
     return g;
 }
 
@@ -107,6 +113,28 @@ __device__ __forceinline__ float grid_pos(float x, const Grid g, float shift, fl
 __device__ __forceinline__ float grid_val(float t, const Grid g) { return t * g.step + g.zero; }
 __device__ __forceinline__ float grid_value(float x, const Grid g) {
     return grid_val(grid_pos(x, g, 0.0f, 0.0f, g.top), g);
+}
+
+// np.digitize(x, limits) for increasing limits: how many of them are <= x (binary search).
+__device__ __forceinline__ int table_index(float x, const Grid g) {
+    const float *lim = g.table + g.n;
+    int lo = 0, hi = g.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (lim[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// The four maps of either kind of codebook (codebook.py:43-95 and 150-190).
+__device__ __forceinline__ float cb_value(float x, const Grid g) { return g.table ? g.table[table_index(x, g)] : grid_value(x, g); }
+__device__ __forceinline__ int cb_index(float x, const Grid g) {
+    return g.table ? table_index(x, g) : (int)grid_pos(x, g, 0.0f, 0.0f, g.top);
+}
+__device__ __forceinline__ float cb_up(float x, const Grid g) {
+    return g.table ? g.table[min(table_index(x, g) + 1, g.n - 1)] : grid_val(grid_pos(x, g, 1.0f, 1.0f, g.top), g);
+}
+__device__ __forceinline__ float cb_down(float x, const Grid g) {
+    return g.table ? g.table[max(table_index(x, g) - 1, 0)] : grid_val(grid_pos(x, g, -1.0f, 0.0f, g.top - 1.0f), g);
 }
 
 // Broadcast lane `src` (wave-uniform index) of a double to the whole wave through SGPRs.

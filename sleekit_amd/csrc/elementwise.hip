@@ -31,13 +31,13 @@ __global__ __launch_bounds__(256) void k_codebook(const float *__restrict__ x, s
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const float v = x[i];
         if (WHAT == SLK_CB_VALUE) {
-            static_cast<float *>(out)[i] = grid_value(v, g);
+            static_cast<float *>(out)[i] = cb_value(v, g);
         } else if (WHAT == SLK_CB_INDEX) {
-            static_cast<uint8_t *>(out)[i] = (uint8_t)grid_pos(v, g, 0.0f, 0.0f, g.top);
+            static_cast<uint8_t *>(out)[i] = (uint8_t)cb_index(v, g);
         } else if (WHAT == SLK_CB_UP) {
-            static_cast<float *>(out)[i] = grid_val(grid_pos(v, g, 1.0f, 1.0f, g.top), g);
+            static_cast<float *>(out)[i] = cb_up(v, g);
         } else {
-            static_cast<float *>(out)[i] = grid_val(grid_pos(v, g, -1.0f, 0.0f, g.top - 1.0f), g);
+            static_cast<float *>(out)[i] = cb_down(v, g);
         }
     }
 }
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_column_miss(const float *__restrict__ W
     float acc = 0.0f;
     for (int r = 0; r < R; ++r) {
         const float w = W[(size_t)r * n + j];
-        const float d = grid_value(w, g) - w;
+        const float d = cb_value(w, g) - w;
         const float t = squared ? d * d : fabsf(d);
         acc = acc + t;
     }
@@ -112,18 +112,18 @@ using namespace slk;
 
 extern "C" {
 
-int slk_abi_version(void) { return 1; }
+int slk_abi_version(void) { return 2; }
 
 const char *slk_last_error(void) { return g_error; }
 
-int slk_codebook_apply(const float *x, size_t count, int levels, double lo, double hi, int what,
+int slk_codebook_apply(const float *x, size_t count, int levels, double lo, double hi, const float *table, int what,
                        void *out, slk_stream_t stream) {
-    SLK_REQUIRE(levels >= 2 && lo < hi, "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
     SLK_REQUIRE(what >= 0 && what <= 3, "unknown codebook map %d", what);
     SLK_REQUIRE(what != SLK_CB_INDEX || levels <= 256, "uint8 indices need levels <= 256");
     if (count == 0) return SLK_OK;
     SLK_REQUIRE(x && out, "null pointer");
-    const Grid g = make_grid(levels, lo, hi);
+    const Grid g = make_grid(levels, lo, hi, table);
     const int blocks = stream_blocks(count, 256 * 4);
     hipStream_t s = as_stream(stream);
     const double bytes = (double)count * (what == SLK_CB_INDEX ? 5.0 : 8.0);
@@ -175,13 +175,13 @@ int slk_hessian_patch_dead(float *H, float *W, int R, int n, void *workspace, si
     return SLK_OK;
 }
 
-int slk_column_miss(const float *W, int R, int n, int levels, double lo, double hi, int squared,
+int slk_column_miss(const float *W, int R, int n, int levels, double lo, double hi, const float *table, int squared,
                     float *miss, slk_stream_t stream) {
-    SLK_REQUIRE(levels >= 2 && lo < hi, "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
     SLK_REQUIRE(R >= 0 && n > 0 && W && miss, "bad arguments");
     hipStream_t s = as_stream(stream);
     SLK_RUN("column_miss", 0, 4.0 * R * n, s,
-            k_column_miss<<<(n + 255) / 256, 256, 0, s>>>(W, R, n, make_grid(levels, lo, hi), squared, miss));
+            k_column_miss<<<(n + 255) / 256, 256, 0, s>>>(W, R, n, make_grid(levels, lo, hi, table), squared, miss));
     return SLK_OK;
 }
 

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_permute_out(const float *__restrict__ Q
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
             const float v = src[inv_order[j]];
             Q[(size_t)r * n + j] = v;
-            if (idx) idx[(size_t)r * n + j] = (uint8_t)grid_pos(v, g, 0.0f, 0.0f, g.top);
+            if (idx) idx[(size_t)r * n + j] = (uint8_t)cb_index(v, g);
         }
     }
 }
@@ -84,6 +84,7 @@ struct WindowSmem {
     int odd[2][4];  // per helper wave: a diagonal entry of that block defeats the exact-division shortcut
     float q[RB][WPITCH];
     float e[RB][WPITCH];
+    float cbt[512];  // a general codebook's values and limits (<= 256 entries), copied here for the leaves
 };
 
 // codebook.py:56-65 with the divide replaced by Markstein's sequence: with y = RN(1/step),
@@ -205,6 +206,10 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
     const bool helper = wave >= 4;
     const int ht = t - 256;  // helper thread index
     const int r0 = blockIdx.x * RB;
+    if (IN_LDS && g.table) {  // the leaves search the codebook once per column: keep it next to them
+        for (int i = t; i < 2 * g.n - 1; i += 512) sm.cbt[i] = g.table[i];
+        g.table = sm.cbt;  // visible after the first barrier below
+    }
     const int width = w1 - w0;
     // cycle accounting (debug): wave-uniform accumulators, written out once at the end
     const bool timing = (dbg & 8) && blockIdx.x == 0;
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
             double err = 0.0;
             if (live) {
                 x = qld(myrow, i);
-                q = grid_value(x, g);
+                q = cb_value(x, g);
                 const double uii = staged ? lt.udr[i - a][0] : U[(size_t)i * n + i];
                 err = (double)(x - q) / uii;
             }
@@ -754,12 +759,13 @@ extern "C" int slk_probe_window_cycles(long long *host_out, int reset) {
 }
 
 extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long long *order, const double *U,
-                                 int R, int n, int levels, double lo, double hi, int min_block, int num_blocks,
+                                 int R, int n, int levels, double lo, double hi, const float *table, int min_block, int num_blocks,
                                  float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
                                  slk_stream_t stream) {
     SLK_REQUIRE(W && U && Q, "null pointer");
     SLK_REQUIRE(R > 0 && n > 0, "empty layer");
-    SLK_REQUIRE(levels >= 2 && lo < hi, "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(table == nullptr || levels <= 256, "general codebooks hold at most 256 entries");
     SLK_REQUIRE(idx == nullptr || levels <= 256, "uint8 indices need levels <= 256");
     SLK_REQUIRE(min_block >= 1 && num_blocks >= 1, "min_block_size and num_blocks must be >= 1");
     Arena ws(workspace, ws_bytes);
@@ -771,12 +777,12 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
         return SLK_E_WS;
     }
     hipStream_t s = as_stream(stream);
-    const Grid g = make_grid(levels, lo, hi);
+    const Grid g = make_grid(levels, lo, hi, table);
     // exact-division shortcut of the leaf: needs a sane step whose significand is not all ones
     const float inv_step = 1.0f / g.step;
     unsigned step_bits;
     memcpy(&step_bits, &g.step, 4);
-    const int fast_ok = (step_bits & 0x7FFFFFu) != 0x7FFFFFu && g.step > 9.0e-13f && g.step < 1.0e12f &&
+    const int fast_ok = table == nullptr && (step_bits & 0x7FFFFFu) != 0x7FFFFFu && g.step > 9.0e-13f && g.step < 1.0e12f &&
                         getenv("SLK_NO_FAST_LEAF") == nullptr;
     const int dbg = getenv("SLK_WIN_DBG") ? atoi(getenv("SLK_WIN_DBG")) : 0;
     const bool no_defer = getenv("SLK_NO_DEFER") != nullptr;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_scale_search(const float *__restrict__ 
         const float inv = 1.0f / sc;      // scaling.py:80
         const float err = row_sum_numpy(trees, terms, n, [&](int j) {
             const float x = w[j];
-            const float q = grid_value(x / sc, g) / inv;
+            const float q = cb_value(x / sc, g) / inv;
             const float e = q - x;
             const float e2 = e * e;
             return hdiag ? hdiag[j] * e2 : e2;
@@ -131,12 +131,12 @@ int slk_scale_norm(const float *W, int R, int n, float *scale, slk_stream_t stre
 }
 
 int slk_scale_search(const float *W, const float *base, const float *factors, int n_factors, const float *hdiag, int R,
-                     int n, int levels, double lo, double hi, float *out, slk_stream_t stream) {
+                     int n, int levels, double lo, double hi, const float *table, float *out, slk_stream_t stream) {
     SLK_REQUIRE(W && base && factors && out && R > 0 && n > 0 && n_factors > 0, "bad arguments");
-    SLK_REQUIRE(levels >= 2 && lo < hi, "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
     hipStream_t s = as_stream(stream);
     SLK_RUN("scale_search", 0, 4.0 * R * n, s,
-            k_scale_search<1><<<R, 256, search_smem(n), s>>>(W, base, factors, n_factors, hdiag, R, n, make_grid(levels, lo, hi), out));
+            k_scale_search<1><<<R, 256, search_smem(n), s>>>(W, base, factors, n_factors, hdiag, R, n, make_grid(levels, lo, hi, table), out));
     return SLK_OK;
 }
 

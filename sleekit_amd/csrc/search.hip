@@ -16,10 +16,8 @@
 
 namespace slk {
 
-__device__ __forceinline__ float cand_up(float q, const Grid g) { return grid_val(grid_pos(q, g, 1.0f, 1.0f, g.top), g); }
-__device__ __forceinline__ float cand_down(float q, const Grid g) {
-    return grid_val(grid_pos(q, g, -1.0f, 0.0f, g.top - 1.0f), g);
-}
+__device__ __forceinline__ float cand_up(float q, const Grid g) { return cb_up(q, g); }
+__device__ __forceinline__ float cand_down(float q, const Grid g) { return cb_down(q, g); }
 
 struct Best {
     float v;
@@ -173,7 +171,7 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         const int j = t + 256 * e;
         if (j < n) {
             Q[base + j] = q[e];
-            if (idx) idx[base + j] = (uint8_t)grid_pos(q[e], g, 0.0f, 0.0f, g.top);
+            if (idx) idx[base + j] = (uint8_t)cb_index(q[e], g);
         }
     }
 }
@@ -183,10 +181,10 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 using namespace slk;
 
 extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
-                                double hi, int moves, uint8_t *idx, void *workspace, size_t ws_bytes,
+                                double hi, const float *table, int moves, uint8_t *idx, void *workspace, size_t ws_bytes,
                                 slk_stream_t stream) {
     SLK_REQUIRE(W && Q && H && R > 0 && n > 0 && moves >= 0, "bad arguments");
-    SLK_REQUIRE(levels >= 2 && lo < hi, "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
     SLK_REQUIRE(idx == nullptr || levels <= 256, "uint8 indices need levels <= 256");
     SLK_REQUIRE(n <= 256 * 64, "local search supports n <= 16384");
     Arena ws(workspace, ws_bytes);
@@ -202,7 +200,7 @@ extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R,
     if (rc != SLK_OK) return rc;
     hipStream_t s = as_stream(stream);
     SLK_RUN("extract_diag", 0, 8.0 * n, s, k_extract_diag<<<(n + 255) / 256, 256, 0, s>>>(H, n, hdiag));
-    const Grid g = make_grid(levels, lo, hi);
+    const Grid g = make_grid(levels, lo, hi, table);
     const int ept = (n + 255) / 256;
 #define SLK_LS(E)                                                                                     \
     SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,             \

@@ -37,6 +37,7 @@ struct Window2Smem {
     float q[RB][WPITCH];
     float e[RB][ERING + 4];
     int odd[2][2][4];        // [parity][leaf][helper wave]: a diagonal defeats the exact-division shortcut
+    float cbt[512];          // a general codebook's values and limits (<= 256 entries)
 };
 
 // The leaf chain on registers (see leaf_registers).  FAST: Markstein divisions (exact unless a
@@ -66,7 +67,7 @@ __device__ __forceinline__ void leaf_chain(const LeafTables &lt, int c16, float 
             const double rem = __builtin_fma(-uii, qq, d);
             err = __builtin_fma(rem, rii, qq);
         } else {
-            q = grid_value(xi, g);
+            q = cb_value(xi, g);
             err = (double)(xi - q) / uii;
         }
         const float ef = (float)err;
@@ -113,6 +114,10 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
     const int r0 = blockIdx.x * RB;
     const int np = tab.count;
     const int width = w1 - w0;
+    if (g.table) {  // the leaves search the codebook once per column: keep it next to them
+        for (int i = t; i < 2 * g.n - 1; i += 512) sm.cbt[i] = g.table[i];
+        g.table = sm.cbt;  // visible after the first barrier (B_start)
+    }
     auto ring = [&](int c) { return (c - w0) & (ERING - 1); };
 
     // columns [c_lo, c_hi) of the Q tile, global -> LDS, by `nth` threads of which this is number `tid`:

@@ -14,7 +14,7 @@ import torch
 
 from . import _device as dev
 from . import _lib
-from .codebook import UniformCodebook
+from .codebook import DeviceCodebook
 
 _INVERSE_ORDERS = {"inv_diag": 0, "combined_diag": 1}  # need diag(Hd^-1): two factorisations
 _KEY_ORDERS = ("inv_diag", "combined_diag", "pivot")     # sort keys computed by a kernel of their own
@@ -58,9 +58,10 @@ def order_keys(H, n, damp, act_order):
 
 
 def require_uniform(quantizer):
-    if not isinstance(quantizer, UniformCodebook):
+    """(levels, lo, hi, table) of a UniformCodebook or a general Codebook; anything else has no device form."""
+    if not isinstance(quantizer, DeviceCodebook):
         raise NotImplementedError(
-            "sleekit_amd runs UniformCodebook quantizers on the GPU and has no CPU fallback for arbitrary "
+            "sleekit_amd runs UniformCodebook / Codebook quantizers on the GPU and has no CPU fallback for arbitrary "
             f"callables (got {type(quantizer).__name__})"
         )
     if len(quantizer) > 256:
@@ -113,14 +114,14 @@ def factorize_order_only(H, n, mode, miss=None):
 def run_loop(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=True, want_E=False):
     """The column-sequential loop on device tensors. Returns (Q, idx, E)."""
     R, n = W.shape
-    levels, lo, hi = cb_abi
+    levels, lo, hi, table = cb_abi
     ws, ws_bytes = dev.workspace(R, n)
     Q = torch.empty((R, n), dtype=torch.float32, device=W.device)
     idx = torch.empty((R, n), dtype=torch.uint8, device=W.device) if want_idx else None
     E = torch.empty((R, n), dtype=torch.float32, device=W.device) if want_E else None
     _lib.check(
         _lib.lib.slk_gptq_quantize(
-            dev.ptr(W), dev.ptr(scale), dev.ptr(order), dev.ptr(U), R, n, levels, lo, hi, int(min_block),
+            dev.ptr(W), dev.ptr(scale), dev.ptr(order), dev.ptr(U), R, n, levels, lo, hi, dev.ptr(table), int(min_block),
             int(num_blocks), dev.ptr(Q), dev.ptr(idx), dev.ptr(E), dev.ptr(ws), ws_bytes, dev.stream_handle(),
         )
     )
@@ -130,11 +131,11 @@ def run_loop(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=True, w
 def local_search(W, Q, H, cb_abi, moves, idx=None):
     """In place on Q (and idx)."""
     R, n = W.shape
-    levels, lo, hi = cb_abi
+    levels, lo, hi, table = cb_abi
     ws, ws_bytes = dev.workspace(R, n)
     _lib.check(
         _lib.lib.slk_local_search(
-            dev.ptr(W), dev.ptr(Q), dev.ptr(H), R, n, levels, lo, hi, int(moves), dev.ptr(idx), dev.ptr(ws),
+            dev.ptr(W), dev.ptr(Q), dev.ptr(H), R, n, levels, lo, hi, dev.ptr(table), int(moves), dev.ptr(idx), dev.ptr(ws),
             ws_bytes, dev.stream_handle(),
         )
     )
@@ -151,10 +152,12 @@ def rows_divide(x, scale, invert=False):
 
 def column_miss(W, cb_abi, squared):
     R, n = W.shape
-    levels, lo, hi = cb_abi
+    levels, lo, hi, table = cb_abi
     out = torch.empty(n, dtype=torch.float32, device=W.device)
     _lib.check(
-        _lib.lib.slk_column_miss(dev.ptr(W), R, n, levels, lo, hi, 1 if squared else 0, dev.ptr(out), dev.stream_handle())
+        _lib.lib.slk_column_miss(
+            dev.ptr(W), R, n, levels, lo, hi, dev.ptr(table), 1 if squared else 0, dev.ptr(out), dev.stream_handle()
+        )
     )
     return out
 

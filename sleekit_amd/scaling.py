@@ -125,10 +125,10 @@ def compute_min_mse_scaling(data, codebook, axis=0, H=None, min_factor=0.05, max
             assert hd.shape[0] == n
         fac = torch.from_numpy(factors).to(W.device)
         out = torch.empty(R, dtype=torch.float32, device=W.device)
-        levels, lo, hi = cb_abi
+        levels, lo, hi, table = cb_abi
         _lib.check(
             _lib.lib.slk_scale_search(
-                dev.ptr(W), dev.ptr(base), dev.ptr(fac), len(factors), dev.ptr(hd), R, n, levels, lo, hi, dev.ptr(out),
+                dev.ptr(W), dev.ptr(base), dev.ptr(fac), len(factors), dev.ptr(hd), R, n, levels, lo, hi, dev.ptr(table), dev.ptr(out),
                 dev.stream_handle(),
             )
         )

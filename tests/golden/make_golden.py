@@ -36,7 +36,7 @@ from sleekit_amd import synth  # noqa: E402
 
 import sleekit.obq as ref_obq  # noqa: E402
 import sleekit.scaling as ref_scaling  # noqa: E402
-from sleekit.codebook import UniformCodebook  # noqa: E402
+from sleekit.codebook import Codebook, UniformCodebook  # noqa: E402
 
 
 def sha(a):
@@ -122,6 +122,20 @@ def pieces():
     cb = UniformCodebook(5, -0.75, 1.25)  # asymmetric grid
     for k in ("value", "index", "up", "down"):
         P[f"cb/asym/{k}"] = getattr(cb, "quantize_" + k)(x)
+
+    # --- general (table) codebooks (codebook.py:98-190): NF4 and an irregular one with explicit limits ---
+    tables = {"nf4": Codebook.nf4(), "odd": Codebook([-1.5, -0.4, -0.1, 0.3, 2.0], [-1.0, -0.2, 0.1, 0.5])}
+    for tag, cb in tables.items():
+        P[f"cbt/{tag}/values"] = cb.values
+        P[f"cbt/{tag}/limits"] = cb.thresholds
+        for k in ("value", "index", "up", "down"):
+            P[f"cbt/{tag}/{k}"] = getattr(cb, "quantize_" + k)(x)
+    # whole layers through quantize_with_scaling with NF4: orders that call the quantizer, and local search
+    for R_, n_, seed_ in ((64, 96, 2001), (96, 172, 2003)):
+        Lt = synth.make_layer(R_, n_, seed_)
+        for order, moves in (("diag", 0), ("sqerr", 0), ("err", 10), ("diag", 10)):
+            out = ref_scaling.quantize_with_scaling(Lt["W"], Lt["scale"], Codebook.nf4(), H=Lt["H"], act_order=order, damp=0.01, nb_ls_moves=moves)
+            P[f"cbt/nf4/layer_r{R_}_n{n_}_s{seed_}_{order}_ls{moves}"] = out
 
     # --- greedy pivoted-Cholesky order (obq.py:140-166) on damped float64 Hessians ---
     for tag, (R_, n_, seed_) in (("96", (64, 96, 2001)), ("256", (32, 256, 2050))):

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_sizes():
     from sleekit_amd import _lib
 
-    assert _lib.lib.slk_abi_version() == 1
+    assert _lib.lib.slk_abi_version() == 2
     assert _lib.lib.slk_factor_ld(1) == 64 and _lib.lib.slk_factor_ld(64) == 64 and _lib.lib.slk_factor_ld(11008) == 11008
     assert _lib.lib.slk_factor_ld(1100) == 1152
     # 4096 x 4096: two float64 n x n scratch matrices dominate
@@ -45,9 +45,9 @@ def test_argument_errors_do_not_touch_the_gpu():
     """Bad arguments are rejected on the host before any launch (safe without a GPU)."""
     from sleekit_amd import _lib
 
-    assert _lib.lib.slk_codebook_apply(None, 4, 1, -1.0, 1.0, 0, None, None) == _lib.E_ARG
+    assert _lib.lib.slk_codebook_apply(None, 4, 1, -1.0, 1.0, None, 0, None, None) == _lib.E_ARG
     assert b"levels" in _lib.lib.slk_last_error()
-    assert _lib.lib.slk_gptq_quantize(None, None, None, None, 4, 4, 8, -1.0, 1.0, 32, 8, None, None, None, None, 0, None) == _lib.E_ARG
+    assert _lib.lib.slk_gptq_quantize(None, None, None, None, 4, 4, 8, -1.0, 1.0, None, 32, 8, None, None, None, None, 0, None) == _lib.E_ARG
     assert _lib.lib.slk_hessian_prepare(None, 0, 0.01, 1, None, None, None, None, 0, None) == _lib.E_ARG
     with pytest.raises(RuntimeError):
         _lib.check(_lib.E_ARG)

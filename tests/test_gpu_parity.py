@@ -329,6 +329,35 @@ def test_orders_from_the_inverse_diagonal(amd, order):
         assert np.array_equal(got, want), (order, n)
 
 
+def test_table_codebook(amd, pieces):
+    """codebook.py:98-190: the general codebook on the GPU -- the four maps bit for bit, then whole layers
+    (orders that call the quantizer, local search with its up / down candidates) against the reference's outputs."""
+    x = pieces["cb/x"]
+    for tag in ("nf4", "odd"):
+        cb = amd.codebook.Codebook(pieces[f"cbt/{tag}/values"], pieces[f"cbt/{tag}/limits"])
+        for k in ("value", "index", "up", "down"):
+            got = getattr(cb, "quantize_" + k)(x)
+            assert got.dtype == pieces[f"cbt/{tag}/{k}"].dtype and np.array_equal(got, pieces[f"cbt/{tag}/{k}"]), (tag, k)
+    nf4 = amd.codebook.Codebook.nf4()
+    assert len(nf4) == 16 and nf4.min() == -1.0 and nf4.max() == 1.0
+    assert np.array_equal(nf4.values, pieces["cbt/nf4/values"]) and np.array_equal(nf4.thresholds, pieces["cbt/nf4/limits"])
+    for R, n, seed in ((64, 96, 2001), (96, 172, 2003)):
+        L = layer(R, n, seed)
+        for order, moves in (("diag", 0), ("sqerr", 0), ("err", 10), ("diag", 10)):
+            want = pieces[f"cbt/nf4/layer_r{R}_n{n}_s{seed}_{order}_ls{moves}"]
+            got = amd.scaling.quantize_with_scaling(L["W"], L["scale"], nf4, L["H"], act_order=order, damp=0.01, nb_ls_moves=moves)
+            assert np.array_equal(got, want), (n, order, moves)
+    # a wide layer: the standard-schedule window kernel with a table in LDS, against the oracle
+    L = layer(40, 1024, 2060)
+    want = scaling_ref.quantize_scaled(L["W"], L["scale"], grid.TableGrid.nf4(), L["H"], "diag", 0.01, 0)
+    got = amd.scaling.quantize_with_scaling(L["W"], L["scale"], nf4, L["H"], act_order="diag", damp=0.01)
+    assert np.array_equal(got, want)
+    with pytest.raises(NotImplementedError):
+        amd.codebook.lloyd_max(L["W"], 16)
+    with pytest.raises(NotImplementedError):
+        nf4.improve(L["W"].reshape(-1))
+
+
 def test_pivot_order(amd, pieces):
     """obq.py:140-166: greedy pivoted Cholesky.  The order against the reference's own (fixture), then a
     layer quantized in that order against the oracle."""

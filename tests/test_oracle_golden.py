@@ -147,6 +147,24 @@ def test_inverse_diagonal_orders_match_reference():
         assert np.array_equal(obq_ref.column_order(L["W"], Hd, None, mode), want)
 
 
+def test_table_codebook_matches_reference(pieces):
+    """codebook.py:98-190: the general codebook (np.digitize on the bin limits), maps and whole layers."""
+    x = pieces["cb/x"]
+    for tag in ("nf4", "odd"):
+        g = grid.TableGrid(pieces[f"cbt/{tag}/values"], pieces[f"cbt/{tag}/limits"])
+        for k in ("value", "index", "up", "down"):
+            got = getattr(g, "quantize_" + k)(x)
+            assert got.dtype == pieces[f"cbt/{tag}/{k}"].dtype and np.array_equal(got, pieces[f"cbt/{tag}/{k}"]), (tag, k)
+    assert np.array_equal(grid.TableGrid.nf4().values, pieces["cbt/nf4/values"])
+    assert np.array_equal(grid.TableGrid.nf4().limits, pieces["cbt/nf4/limits"])
+    for R, n, seed in ((64, 96, 2001), (96, 172, 2003)):
+        L = layer(R, n, seed)
+        for order, moves in (("diag", 0), ("sqerr", 0), ("err", 10), ("diag", 10)):
+            want = pieces[f"cbt/nf4/layer_r{R}_n{n}_s{seed}_{order}_ls{moves}"]
+            got = scaling_ref.quantize_scaled(L["W"], L["scale"], grid.TableGrid.nf4(), L["H"], order, 0.01, moves)
+            assert np.array_equal(got, want), (n, order, moves)
+
+
 def test_pivot_order_matches_reference(pieces):
     """obq.py:140-166: the greedy pivoted-Cholesky order, restated without the trailing matrix."""
     for tag, (R, n, seed) in (("96", (64, 96, 2001)), ("256", (32, 256, 2050))):

@@ -5,8 +5,8 @@ Same names, arguments, defaults and error behaviour as the reference module
 may be NumPy arrays (results come back as new NumPy arrays, like the reference) or torch
 tensors already on the GPU (results stay there; nothing synchronises).
 
-Outside the accelerated path -- present, but raising NotImplementedError: quantizers
-other than UniformCodebook, and the `pivot` ordering.
+Quantizers are `UniformCodebook` or the general `Codebook` (sleekit_amd.codebook); arbitrary Python
+callables have no device form and raise NotImplementedError.
 """
 
 import numpy as np

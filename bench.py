@@ -38,11 +38,11 @@ import torch.distributed as dist
 
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md; float64 from the CDNA4 datasheet:
 # vector = matrix = 78.6 TFLOP/s, i.e. 32 flop/clk/SIMD at 2.4 GHz on 1024 SIMDs)
-PEAK = {"hbm": (8.0e12, "GB/s"), "mfma_f64": (78.6e12, "TFLOP/s"), "mfma_f32": (157.3e12, "TFLOP/s")}
+PEAK = {"hbm": (8.0e12, "GB/s"), "mfma_f64": (78.6e12, "TFLOP/s"), "mfma_f32": (157.3e12, "TFLOP/s"), "mfma_bf16": (2.5e15, "TFLOP/s")}
 KERNEL_DTYPE = {
     "chol_panel": "mfma_f64", "chol_syrk_inner": "mfma_f64", "chol_syrk_outer": "mfma_f64", "trtri_stage0": "mfma_f64", "trtri_stage1": "mfma_f64",
     "gptq_window": "mfma_f64", "gptq_window_wide": "mfma_f64", "gptq_trailing": "mfma_f64",
-    "error_gemm": "mfma_f32", "hessian_syrk": "mfma_f32",
+    "error_gemm": "mfma_f32", "error_gemm_bf16": "mfma_bf16", "hessian_syrk": "mfma_f32",
 }
 
 

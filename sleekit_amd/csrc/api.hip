@@ -115,10 +115,13 @@ size_t slk_workspace_bytes(int R, int n) {
     size_t factor = 2 * ld * ld * sizeof(double);                      // X and S of slk_chol_inverse_upper
     size_t loop = 2 * rn * sizeof(float) + (size_t)n * sizeof(int);    // permuted Q and E, inverse order
     size_t search = rn * sizeof(float) + (size_t)(R + n) * sizeof(float) + (size_t)R * ((n + 127) / 128) * sizeof(float) + 4096;
+    // layer error on the bfloat16 MFMA: three 2-byte planes of W - Q and of H, the per-tile partial sums
+    size_t error = 6 * (rn + 128 * (size_t)n) + 6 * (size_t)n * n + (size_t)R * ((n + 127) / 128) * sizeof(float) + 8192;
     size_t prep = 64 * sizeof(float) + (size_t)n * (sizeof(double) + 1);
     size_t m = factor;
     if (loop > m) m = loop;
     if (search > m) m = search;
+    if (error > m) m = error;
     if (prep > m) m = prep;
     return m + (1u << 16);
 }

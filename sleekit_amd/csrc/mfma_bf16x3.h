@@ -1,0 +1,109 @@
+// float32-grade products on the bfloat16 MFMA: each float32 operand is split into three bfloat16 pieces
+// (a = a1 + a2 + a3 exactly, to 24 bits) and the product takes the six piece products above 2^-24,
+//     a b ~ a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1),
+// every one exact in float32, accumulated in float32 by v_mfma_f32_32x32x16_bf16 (smallest terms first).
+// Measured (tools/scratch/mfma_bf16.hip): error / sum|a b| = 9e-8 ... 1.7e-7 for K = 512 ... 4096, the same as a
+// sequential float32 fma chain (1.3e-7).  The bfloat16 MFMA does 16x the float32 MFMA's flops per cycle, so six
+// terms cost 3/8 of the float32 instruction stream.
+//
+// One 256-thread workgroup accumulates a 128 x 128 tile; wave w owns the 64 x 64 sub-tile (w >> 1, w & 1) as
+// 2 x 2 blocks of 32 x 32.  BOTH operands are given K-contiguous: A[row][k] and Bt[col][k] (the callers' B is
+// symmetric, so B[k][col] = B[col][k] and its rows serve), already split into three bfloat16 planes in the
+// slab order of k_split3 (splitting in the loop was measured: 656 us against 550, the vector ALU work of
+// 7.5 instructions per element and tile).  K goes in steps of 32 through LDS: three planes per operand,
+// [row][32 k] bfloat16 with a pitch of 80 bytes, which makes the 16-byte operand reads (lane l: row l & 31,
+// k group l >> 5) conflict-free over ds_read_b128's 16-lane groups.
+//
+// Operand maps of v_mfma_f32_32x32x16_bf16 (checked by the scratch program above):
+//   A: lane l holds A[row = l & 31][k = 8 (l >> 5) .. + 7]    B: lane l holds B[k = 8 (l >> 5) .. + 7][col = l & 31]
+//   D: as v_mfma_f32_32x32x2_f32 (mfma32.h)
+#pragma once
+
+#include "mfma32.h"
+
+namespace slk {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned uint4v_t __attribute__((ext_vector_type(4)));
+
+constexpr int KB16 = 32;          // K depth per LDS round
+constexpr int PITCH_B16 = 80;     // bytes per staged row of one plane (64 of data)
+
+struct TileBf16Smem {
+    unsigned char a[3][T32 * PITCH_B16];
+    unsigned char b[3][T32 * PITCH_B16];
+};
+
+// Two floats -> three words holding their bfloat16 pieces pairwise (round to nearest even at each level:
+// v_cvt_pk_bf16_f32, gfx950's hardware conversion; the residuals x - piece are exact in float32).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned &w1, unsigned &w2, unsigned &w3) {
+    const __bf16 x1 = (__bf16)x, y1 = (__bf16)y;
+    const float rx = x - (float)x1, ry = y - (float)y1;
+    const __bf16 x2 = (__bf16)rx, y2 = (__bf16)ry;
+    const float sx = rx - (float)x2, sy = ry - (float)y2;
+    const __bf16 x3 = (__bf16)sx, y3 = (__bf16)sy;
+    w1 = __builtin_bit_cast(unsigned, (bf16x2_t){x1, y1});
+    w2 = __builtin_bit_cast(unsigned, (bf16x2_t){x2, y2});
+    w3 = __builtin_bit_cast(unsigned, (bf16x2_t){x3, y3});
+}
+
+// acc += A(128 x K) * Bt(128 x K)^T from operands split beforehand (k_split3 in sgemm.hip): plane p of A is a row-major
+// bfloat16 image A_p[row][k], likewise Bt_p[col][k].  The loop then has no vector arithmetic at all: six
+// 16-byte loads per operand and round, twelve LDS writes, the reads and the MFMAs.
+// la(k0, v) / lb(k0, v): v[p][h] = 16 bytes h of plane p of this thread's row (threadIdx.x >> 1), k = k0 + 16 (threadIdx.x & 1) + 8 h ...
+template <class LA, class LB>
+__device__ __forceinline__ void tile128_mac_planes(Acc128 &acc, TileBf16Smem &sm, int k_begin, int k_end, LA la, LB lb) {
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // (Loads two rounds ahead in two register sets were tried -- a round's MFMAs last less than a trip to
+    // memory -- and were slower, 608 vs 550 us: 220 registers, and the bound is elsewhere.)
+    uint4v_t ra[3][2], rb[3][2];
+    const int s_off = (t >> 1) * PITCH_B16 + (t & 1) * 32;
+    if (k_begin >= k_end) return;
+    la(k_begin, ra);
+    lb(k_begin, rb);
+    const int r_off = (lane & 31) * PITCH_B16 + (lane >> 5) * 16;
+    for (int k0 = k_begin; k0 < k_end; k0 += KB16) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                *reinterpret_cast<uint4v_t *>(sm.a[p] + s_off + 16 * h) = ra[p][h];
+                *reinterpret_cast<uint4v_t *>(sm.b[p] + s_off + 16 * h) = rb[p][h];
+            }
+        __syncthreads();
+        if (k0 + KB16 < k_end) {
+            la(k0 + KB16, ra);
+            lb(k0 + KB16, rb);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[i][p] = *reinterpret_cast<const bf16x8_t *>(sm.a[p] + (wr * 64 + i * 32) * PITCH_B16 + r_off + s * 32);
+                    b[i][p] = *reinterpret_cast<const bf16x8_t *>(sm.b[p] + (wc * 64 + i * 32) * PITCH_B16 + r_off + s * 32);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float16_t c = acc.c[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+                    acc.c[i][j] = c;
+                }
+        }
+    }
+}
+
+}  // namespace slk

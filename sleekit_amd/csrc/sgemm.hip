@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "mfma32.h"
+#include "mfma_bf16x3.h"
 
 namespace slk {
 
@@ -16,7 +17,8 @@ namespace slk {
 __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W, const float *__restrict__ Q,
                                                      const float *__restrict__ H, int R, int n,
                                                      float *__restrict__ G, float *__restrict__ partial,
-                                                     int n_tiles, int vec_ok, const int *__restrict__ sym_flag) {
+                                                     int n_tiles, int vec_ok, const int *__restrict__ sym_flag,
+                                                     int bf16_takes_sym) {
     __shared__ Tile128Smem sm;
     __shared__ float rowpart[2][T32];
     // Column tiles are rotated by the row-tile index: with the symmetric shortcut below a tile's
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
     //   sum_k D_k H_kj over all k  ==  2 * sum_{k < j0} + the 128-wide diagonal band, after the
     //   final multiplication by D_j and the sum over j.  Halves the flops of the layer error.
     const bool sym = sym_flag != nullptr && sym_flag[0] != 0;
+    if (sym && bf16_takes_sym) return;
     const int kend = sym ? min(j0 + T32, kfull) : kfull;
     const int ksplit = sym ? j0 : 0;  // [0, ksplit) counted twice
     const int a_row = r0 + (t >> 1), a_k = (t & 1) * 8;  // A: D = W - Q, K contiguous
@@ -131,6 +134,126 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
                 }
             }
             // reduce over the 32 lanes that share this row
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
+            if ((lane & 31) == 0) rowpart[wc][row] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < T32 && r0 + threadIdx.x < R)
+        partial[(size_t)(r0 + threadIdx.x) * n_tiles + tile_x] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
+}
+
+// x (or x - y when y is given), rows x n row-major -> its three bfloat16 pieces in the GEMM's own order:
+// plane p at out + p * plane, and inside a plane the slab (128-row block rb, 32-deep k step ks) is one
+// contiguous 8 KB run, [row in block][32 k] -- what a workgroup of k_error_tiles_bf16 loads per round, so
+// its 16-byte loads walk memory linearly (row-major planes gave 64 contiguous bytes per row and round).
+// Rows beyond `rows` in the last block repeat the last row (never stored by the GEMM).  n % 32 == 0.
+// One pass at HBM speed; it takes all the splitting arithmetic out of the GEMM, where every element
+// would otherwise be split once per tile that uses it (32 times at n = 4096).
+__global__ __launch_bounds__(256) void k_split3(const float *__restrict__ x, const float *__restrict__ y, int rows, int n,
+                                                unsigned short *__restrict__ out, size_t plane,
+                                                const int *__restrict__ sym_flag) {
+    if (sym_flag[0] == 0) return;
+    const int ksteps = n / 32;
+    const size_t quads = plane / 4;  // groups of four consecutive k
+    for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = qd * 4;                      // position in the plane
+        const int k4 = (int)(e & 31), r = (int)((e >> 5) & 127);
+        const size_t slab = e >> 12;                  // rb * ksteps + ks
+        const int ks = (int)(slab % ksteps), rb = (int)(slab / ksteps);
+        const int row = min(rb * 128 + r, rows - 1);
+        const size_t src = (size_t)row * n + ks * 32 + k4;
+        float4_t v = *reinterpret_cast<const float4_t *>(x + src);
+        if (y) {
+            const float4_t u = *reinterpret_cast<const float4_t *>(y + src);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = v[c] - u[c];
+        }
+        unsigned w[3][2];
+        split3_pair(v[0], v[1], w[0][0], w[1][0], w[2][0]);
+        split3_pair(v[2], v[3], w[0][1], w[1][1], w[2][1]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            unsigned *o = reinterpret_cast<unsigned *>(out + (size_t)p * plane + e);
+            o[0] = w[p][0];
+            o[1] = w[p][1];
+        }
+    }
+}
+
+// The symmetric case on the bfloat16 MFMA (mfma_bf16x3.h): same tile order, same epilogue, the product
+// emulated to float32 grade with six bfloat16 terms from operands split by k_split3.  Runs only when the
+// device-side flag says H is symmetric (its rows then serve as the K-contiguous B operand) -- the float32
+// kernel above takes the other case; each returns at once when the flag is not its own.  n % 128 == 0.
+__global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restrict__ W, const float *__restrict__ Q,
+                                                          const unsigned short *__restrict__ Dp,
+                                                          const unsigned short *__restrict__ Hp, int R, int n,
+                                                          float *__restrict__ partial, int n_tiles,
+                                                          const int *__restrict__ sym_flag) {
+    if (sym_flag[0] == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TileBf16Smem &sm = *reinterpret_cast<TileBf16Smem *>(smem_raw);
+    __shared__ float rowpart[2][T32];
+    const int n_rt = (R + T32 - 1) / T32, n_all = n_tiles * n_rt;
+    const int per_xcd = (n_all + 7) / 8;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= n_all) return;
+    const int tile_y = lin / n_tiles, in_row = lin - tile_y * n_tiles;
+    const int rot = (in_row + tile_y * max(1, n_tiles / 4)) % n_tiles;
+    const int tile_x = (tile_y & 1) ? n_tiles - 1 - rot : rot;
+    const int r0 = tile_y * T32, j0 = tile_x * T32;
+    const int t = threadIdx.x;
+    Acc128 acc;
+    acc.zero();
+    // slab (row block, k step) of a plane: 128 x 32 bfloat16, this thread's 32 bytes at (t >> 1, 16 (t & 1))
+    const int ksteps = n / 32;
+    const size_t d_plane = (size_t)n_rt * T32 * n, h_plane = (size_t)n * n;
+    const unsigned short *pd = Dp + (size_t)tile_y * ksteps * 4096 + (size_t)t * 16;
+    const unsigned short *ph = Hp + (size_t)tile_x * ksteps * 4096 + (size_t)t * 16;
+    auto la = [&](int k0, uint4v_t(&v)[3][2]) {
+        const unsigned short *q = pd + (size_t)(k0 >> 5) * 4096;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[p][h] = *reinterpret_cast<const uint4v_t *>(q + p * d_plane + 8 * h);
+    };
+    auto lb = [&](int k0, uint4v_t(&v)[3][2]) {
+        const unsigned short *q = ph + (size_t)(k0 >> 5) * 4096;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[p][h] = *reinterpret_cast<const uint4v_t *>(q + p * h_plane + 8 * h);
+    };
+    // sum_k D_k H_kj over all k == 2 * sum_{k < j0} + the 128-wide diagonal band (see k_error_tiles)
+    if (j0 > 0) {
+        tile128_mac_planes(acc, sm, 0, j0, la, lb);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.c[i][j][r] = acc.c[i][j][r] * 2.0f;
+        __syncthreads();
+    }
+    tile128_mac_planes(acc, sm, j0, j0 + T32, la, lb);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = j0 + wc * 64 + j * 32 + (lane & 31);
+                if (r0 + row < R) {
+                    const size_t o = (size_t)(r0 + row) * n + col;
+                    s = s + acc.c[i][j][r] * (W[o] - Q[o]);
+                }
+            }
 #pragma unroll
             for (int m = 16; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
             if ((lane & 31) == 0) rowpart[wc][row] = s;
@@ -248,9 +371,30 @@ int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n,
         const int t32 = (n + 31) / 32;
         SLK_RUN("symmetry_check", 0, 4.0 * n * n, s, k_symmetry_flag<<<dim3(t32, t32), 256, 0, s>>>(H, n, sym));
     }
+    // the symmetric case goes to the bfloat16 x 3 kernel when the shape allows (16-byte loads, whole tiles of columns)
+    const size_t d_plane = (size_t)((R + T32 - 1) / T32) * T32 * n;  // rows padded to whole tiles
+    unsigned short *Dp = ws.take<unsigned short>(3 * d_plane), *Hp = ws.take<unsigned short>(3 * (size_t)n * n);
+    const int bf16_ok = try_sym && vec_ok && n % T32 == 0 && Dp && Hp && getenv("SLK_NO_BF16_ERROR") == nullptr;
     // algorithmic flops: the definition (2 R n^2) whichever way they are obtained
-    SLK_RUN("error_gemm", 2.0 * R * n * n, 8.0 * R * n + 4.0 * n * n + (G ? 4.0 * R * n : 0.0), s,
-            k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles, vec_ok, try_sym ? sym : nullptr));
+    if (bf16_ok) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_error_tiles_bf16),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TileBf16Smem)));
+            attr_set = true;
+        }
+        SLK_RUN("error_split", 0, 14.0 * R * n + 10.0 * n * n, s, k_split3<<<2048, 256, 0, s>>>(W, Q, R, n, Dp, d_plane, sym));
+        SLK_RUN("error_split", 0, 0, s, k_split3<<<2048, 256, 0, s>>>(H, nullptr, n, n, Hp, (size_t)n * n, sym));
+        // flops as executed: six bfloat16 products per float32 product, over k <= j only (the definition of the
+        // layer error, SURVEY.md 8d, counts 2 R n^2 float32 flops: a third of this, twice over)
+        SLK_RUN("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n, s,
+                k_error_tiles_bf16<<<grid, 256, sizeof(TileBf16Smem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym));
+        SLK_RUN("error_gemm_f32", 0, 0, s,
+                k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles, vec_ok, sym, 1));
+    } else {
+        SLK_RUN("error_gemm", 2.0 * R * n * n, 8.0 * R * n + 4.0 * n * n + (G ? 4.0 * R * n : 0.0), s,
+                k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles, vec_ok, try_sym ? sym : nullptr, 0));
+    }
     SLK_RUN("error_reduce", 0, 4.0 * R * n_tiles, s, k_error_reduce<<<(R + 255) / 256, 256, 0, s>>>(partial, R, n_tiles, row_err));
     return SLK_OK;
 }

@@ -329,6 +329,32 @@ def test_orders_from_the_inverse_diagonal(amd, order):
         assert np.array_equal(got, want), (order, n)
 
 
+def test_layer_error_bf16_path(amd, monkeypatch):
+    """The layer error of a symmetric Hessian runs on the bfloat16 MFMA with three pieces per operand
+    (six products): every row within 1e-5 of the float64 value, like the float32 kernel it replaces --
+    ragged row count, float32-MFMA path forced for comparison, and an asymmetric H (float32 kernel, all of H)."""
+    rng = np.random.default_rng(11)
+    R, n = 200, 1024
+    W = rng.standard_normal((R, n)).astype(np.float32)
+    Q = (W + 0.2 * rng.standard_normal((R, n))).astype(np.float32)
+    X = rng.standard_normal((2 * n, n)).astype(np.float32)
+    H = (X.T @ X / (2 * n)).astype(np.float32)
+    H = ((H + H.T) * np.float32(0.5)).astype(np.float32)
+    D = (W - Q).astype(np.float64)
+    want = ((D @ H.astype(np.float64)) * D).sum(axis=1)
+    got = amd.obq.channelwise_error(W, Q, H)
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+    monkeypatch.setenv("SLK_NO_BF16_ERROR", "1")
+    got32 = amd.obq.channelwise_error(W, Q, H)
+    monkeypatch.delenv("SLK_NO_BF16_ERROR")
+    np.testing.assert_allclose(got32, want, rtol=1e-5)
+    np.testing.assert_allclose(got, got32, rtol=2e-6)
+    Ha = H.copy()
+    Ha[3, 7] += np.float32(0.25)  # not symmetric: every k is multiplied
+    want_a = ((D @ Ha.astype(np.float64)) * D).sum(axis=1)
+    np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, Ha), want_a, rtol=1e-5)
+
+
 def test_table_codebook(amd, pieces):
     """codebook.py:98-190: the general codebook on the GPU -- the four maps bit for bit, then whole layers
     (orders that call the quantizer, local search with its up / down candidates) against the reference's outputs."""

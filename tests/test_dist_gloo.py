@@ -69,7 +69,8 @@ def _worker(rank, size, port, q):
         be = FakeBackend()
         shards = sdist.quantize_stream(layers, be)
         errs = [float(sdist.layer_error(s["row_err"], layers[i]["W"].shape[0])) for i, s in enumerate(shards)]
-        q.put((rank, be.factored, [(s["rows"], s["Q"]) for s in shards], errs))
+        # by value (NumPy): a torch tensor travels as a shared-memory handle that dies with this process
+        q.put((rank, be.factored, [(s["rows"], s["Q"].numpy().copy()) for s in shards], errs))
     finally:
         dist.destroy_process_group()
 
@@ -111,6 +112,6 @@ def test_stream_over_gloo_world2():
         (lo0, hi0), q0 = got[0][2][l]
         (lo1, hi1), q1 = got[1][2][l]
         assert (lo0, hi1) == (0, R) and hi0 == lo1
-        assert torch.equal(torch.cat([q0, q1]), single[l]["Q"])  # shards == the unsharded result
+        assert torch.equal(torch.cat([torch.from_numpy(q0), torch.from_numpy(q1)]), single[l]["Q"])  # shards == the unsharded result
         want = float(single[l]["row_err"].double().sum() / R)
         assert abs(got[0][3][l] - want) < 1e-9 * abs(want) and got[0][3][l] == got[1][3][l]

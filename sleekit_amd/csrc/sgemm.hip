@@ -195,13 +195,23 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TileBf16Smem &sm = *reinterpret_cast<TileBf16Smem *>(smem_raw);
     __shared__ float rowpart[2][T32];
-    const int n_rt = (R + T32 - 1) / T32, n_all = n_tiles * n_rt;
-    const int per_xcd = (n_all + 7) / 8;
-    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (lin >= n_all) return;
-    const int tile_y = lin / n_tiles, in_row = lin - tile_y * n_tiles;
-    const int rot = (in_row + tile_y * max(1, n_tiles / 4)) % n_tiles;
-    const int tile_x = (tile_y & 1) ? n_tiles - 1 - rot : rot;
+    // XCD-aware tile order, column-major inside the XCD.  Workgroup i runs on XCD i % 8 (own L2).  XCD x takes
+    // the row tiles [x rpx, (x + 1) rpx) (rpx = 4 for a 4096-row layer) and walks the column tiles in the order
+    // `rank`; its slot s = rank * rpx + row, so the workgroups resident together (two per CU, 64 per XCD) are
+    // ALL the band's rows times 16 column tiles: an H slab is fetched once and serves every row of the band, the
+    // band's own D slabs stay in L2.  (Row-major slots left only two of the four rows resident at a time and
+    // cost 1.9 GB past the L2 per launch.)  The column ranks go up and down the depths in groups of 8 so that
+    // the tiles a CU gets over time (slots s, s + 32, ...) add up to the same depth.
+    const int n_rt = (R + T32 - 1) / T32;
+    const int rpx = (n_rt + 7) / 8, per_xcd = rpx * n_tiles;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (slot >= per_xcd) return;
+    const int rank = slot / rpx, tile_y = xcd * rpx + (slot - rank * rpx);
+    if (tile_y >= n_rt) return;
+    const int grp = rank >> 3, in_grp = rank & 7;
+    const int g_lo = grp * 8, g_hi = min(n_tiles, g_lo + 8) - 1;
+    const int tile_x = (grp & 1) ? g_hi - in_grp : g_lo + in_grp;
+    if (tile_x < g_lo || tile_x > g_hi) return;  // a last group shorter than 8
     const int r0 = tile_y * T32, j0 = tile_x * T32;
     const int t = threadIdx.x;
     Acc128 acc;
@@ -387,8 +397,10 @@ int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n,
         SLK_RUN("error_split", 0, 0, s, k_split3<<<2048, 256, 0, s>>>(H, nullptr, n, n, Hp, (size_t)n * n, sym));
         // flops as executed: six bfloat16 products per float32 product, over k <= j only (the definition of the
         // layer error, SURVEY.md 8d, counts 2 R n^2 float32 flops: a third of this, twice over)
+        const int n_rt = (R + T32 - 1) / T32;
+        const dim3 grid16(8 * ((n_rt + 7) / 8) * ((n_tiles + 7) / 8 * 8));  // see the tile order in the kernel
         SLK_RUN("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n, s,
-                k_error_tiles_bf16<<<grid, 256, sizeof(TileBf16Smem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym));
+                k_error_tiles_bf16<<<grid16, 256, sizeof(TileBf16Smem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym));
         SLK_RUN("error_gemm_f32", 0, 0, s,
                 k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles, vec_ok, sym, 1));
     } else {

@@ -87,9 +87,11 @@ int slk_hessian_patch_dead(float *H, float *W, int R, int n, void *workspace, si
 /* a1  Sleekit.add_batch, Linear branch  (sleekit/statistics.py:41-43, 76-87)
  *     X: T tokens x n features, row-major.  With c = count_before, c' = c + T:
  *     mean = mean * (c/c') + colsum(X) / c';   H = H * (c/c') + X^T X / c'.
- *     float32 MFMA; matches the reference to float32 GEMM tolerance.           */
+ *     Matches the reference to float32 GEMM tolerance: float32 MFMA, or -- n a multiple of 128 and a
+ *     workspace given (6 n bytes per token, chunked to what fits) -- float32-grade products of three
+ *     bfloat16 pieces per operand on the bfloat16 MFMA.  workspace may be NULL.                    */
 int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T,
-                           long long count_before, slk_stream_t stream);
+                           long long count_before, void *workspace, size_t ws_bytes, slk_stream_t stream);
 
 /* a4  column statistics for the err / sqerr orders  (sleekit/obq.py:60-69)
  *     miss[j] = sum over rows, in row order, of |q(W) - W| (squared == 0) or its square. */

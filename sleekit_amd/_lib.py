@@ -36,7 +36,7 @@ PROTOTYPES = {
     "slk_rows_divide": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "slk_hessian_strip_mean": (c_int, [P, P, c_int, P, P]),
     "slk_hessian_patch_dead": (c_int, [P, P, c_int, c_int, P, c_size_t, P]),
-    "slk_hessian_accumulate": (c_int, [P, P, P, c_int, c_int, c_longlong, P]),
+    "slk_hessian_accumulate": (c_int, [P, P, P, c_int, c_int, c_longlong, P, c_size_t, P]),
     "slk_column_miss": (c_int, [P, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P]),
     "slk_hessian_prepare": (c_int, [P, c_int, c_float, c_int, P, P, P, P, c_size_t, P]),
     "slk_inverse_diag_keys": (c_int, [P, P, c_int, c_float, c_int, P, P, c_size_t, P]),

@@ -345,6 +345,77 @@ __global__ __launch_bounds__(256) void k_hessian_tiles(float *__restrict__ H, co
     });
 }
 
+// X (T x n, tokens x features) -> the three bfloat16 pieces of its TRANSPOSE in the GEMM's slab order: slab
+// (128-feature block ib, 32-token step ks) is [feature in block][32 tokens], contiguous; tokens beyond T are
+// zero.  One workgroup per slab: 32 coalesced rows of 128 floats in, through LDS, 8 KB per plane out.
+__global__ __launch_bounds__(256) void k_split3_transposed(const float *__restrict__ X, int n, int T, int t_first, int t_count,
+                                                           unsigned short *__restrict__ out, size_t plane) {
+    __shared__ float tile[32][T32 + 1];
+    const int ib = blockIdx.x, ks = blockIdx.y;
+    const int t = threadIdx.x;
+    for (int e = t; e < 32 * T32; e += 256) {
+        const int tt = e >> 7, ii = e & 127;
+        const int tok = t_first + ks * 32 + tt;
+        tile[tt][ii] = (ks * 32 + tt < t_count && tok < T) ? X[(size_t)tok * n + ib * T32 + ii] : 0.0f;
+    }
+    __syncthreads();
+    const int ii = t >> 1, half = (t & 1) * 16;
+    unsigned w[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3_pair(tile[half + 2 * e][ii], tile[half + 2 * e + 1][ii], w[0][e], w[1][e], w[2][e]);
+    const size_t slab = ((size_t)ib * gridDim.y + ks) * 4096 + (size_t)t * 16;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        uint4v_t *o = reinterpret_cast<uint4v_t *>(out + p * plane + slab);
+        o[0] = (uint4v_t){w[p][0], w[p][1], w[p][2], w[p][3]};
+        o[1] = (uint4v_t){w[p][4], w[p][5], w[p][6], w[p][7]};
+    }
+}
+
+// Lower tiles of X^T X on the bfloat16 MFMA (mfma_bf16x3.h), from the planes of k_split3_transposed; same
+// epilogue as k_hessian_tiles.  Tiles of the lower triangle in an XCD-aware order (see k_syrk_triangle).
+__global__ __launch_bounds__(256) void k_hessian_tiles_bf16(float *__restrict__ H, const unsigned short *__restrict__ Xp, int n,
+                                                            int ksteps, size_t plane, float factor, float count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TileBf16Smem &sm = *reinterpret_cast<TileBf16Smem *>(smem_raw);
+    const int m = n / T32, total = m * (m + 1) / 2, per_xcd = (total + 7) / 8;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= total) return;
+    int bi = (int)((sqrtf(8.0f * (float)lin + 1.0f) - 1.0f) * 0.5f);
+    while (bi * (bi + 1) / 2 > lin) --bi;
+    while ((bi + 1) * (bi + 2) / 2 <= lin) ++bi;
+    const int bj = lin - bi * (bi + 1) / 2;
+    const int t = threadIdx.x;
+    Acc128 acc;
+    acc.zero();
+    const unsigned short *pa = Xp + (size_t)bi * ksteps * 4096 + (size_t)t * 16;
+    const unsigned short *pb = Xp + (size_t)bj * ksteps * 4096 + (size_t)t * 16;
+    auto la = [&](int k0, uint4v_t(&v)[3][2]) {
+        const unsigned short *q = pa + (size_t)(k0 >> 5) * 4096;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[p][h] = *reinterpret_cast<const uint4v_t *>(q + p * plane + 8 * h);
+    };
+    auto lb = [&](int k0, uint4v_t(&v)[3][2]) {
+        const unsigned short *q = pb + (size_t)(k0 >> 5) * 4096;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[p][h] = *reinterpret_cast<const uint4v_t *>(q + p * plane + 8 * h);
+    };
+    tile128_mac_planes(acc, sm, 0, ksteps * 32, la, lb);
+    const int i0 = bi * T32, j0 = bj * T32;
+    tile128_foreach(acc, [&](int r, int c, float v) {
+        const int i = i0 + r, j = j0 + c;
+        if (bi != bj || j <= i) {
+            const float h = H[(size_t)i * n + j] * factor + v / count;
+            H[(size_t)i * n + j] = h;
+            if (i != j) H[(size_t)j * n + i] = h;
+        }
+    });
+}
+
 __global__ __launch_bounds__(256) void k_mean_update(float *__restrict__ mean, const float *__restrict__ X, int n, int T,
                                                      float factor, float count) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -412,7 +483,7 @@ int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n,
 }
 
 int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, long long count_before,
-                           slk_stream_t stream) {
+                           void *workspace, size_t ws_bytes, slk_stream_t stream) {
     SLK_REQUIRE(H && mean && X && n > 0 && T > 0 && count_before >= 0, "bad arguments");
     const long long after = count_before + T;
     const float factor = (float)((double)count_before / (double)after);
@@ -420,6 +491,31 @@ int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, 
     hipStream_t s = as_stream(stream);
     const int nt = (n + T32 - 1) / T32;
     SLK_RUN("mean_update", 0, 4.0 * T * n, s, k_mean_update<<<(n + 255) / 256, 256, 0, s>>>(mean, X, n, T, factor, count));
+    // bfloat16 x 3 path: whole tiles of features, and room for the planes of at least 32 tokens
+    Arena ws(workspace, ws_bytes);
+    const size_t room = workspace && ws_bytes > 4096 ? (ws_bytes - 4096) / ((size_t)6 * n) / 32 * 32 : 0;  // tokens per chunk
+    if (n % T32 == 0 && room >= 32 && getenv("SLK_NO_BF16_HESSIAN") == nullptr) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hessian_tiles_bf16),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TileBf16Smem)));
+            attr_set = true;
+        }
+        const int chunk = (int)(room < (size_t)((T + 31) / 32 * 32) ? room : (size_t)((T + 31) / 32 * 32));
+        unsigned short *Xp = ws.take<unsigned short>((size_t)3 * n * chunk);
+        const int m = n / T32, total = m * (m + 1) / 2;
+        for (int t0 = 0; t0 < T; t0 += chunk) {
+            const int cnt = T - t0 < chunk ? T - t0 : chunk, ksteps = (cnt + 31) / 32;
+            const size_t plane = (size_t)n * ksteps * 32;
+            SLK_RUN("hessian_split", 0, 10.0 * cnt * n, s,
+                    k_split3_transposed<<<dim3(m, ksteps), 256, 0, s>>>(X, n, T, t0, cnt, Xp, plane));
+            // the running-mean factor applies once per batch: later chunks add to what the first one scaled
+            SLK_RUN("hessian_syrk_bf16", 6.0 * cnt * n * (n + (double)T32), 6.0 * cnt * n + 8.0 * n * n, s,
+                    k_hessian_tiles_bf16<<<8 * ((total + 7) / 8), 256, sizeof(TileBf16Smem), s>>>(H, Xp, n, ksteps, plane,
+                                                                                                  t0 == 0 ? factor : 1.0f, count));
+        }
+        return SLK_OK;
+    }
     dim3 grid(nt, nt);
     SLK_RUN("hessian_syrk", (double)T * n * (n + 1), 4.0 * T * n + 8.0 * n * n, s,
             k_hessian_tiles<<<grid, 256, 0, s>>>(H, X, n, T, factor, count, n % 4 == 0 && (uintptr_t)X % 16 == 0));

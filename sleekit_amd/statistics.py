@@ -3,7 +3,8 @@
 Interface of the reference class (sleekit/statistics.py:12-199, "API compatible with GPTQ"):
 `Sleekit(layer).add_batch(inp)`, `.quantize(nbits, ...)`, the three presets, `.export(path)`, `.free()`.
 
-* `add_batch` (statistics.py:76-87) runs on float32 MFMA through `slk_hessian_accumulate`; the mean
+* `add_batch` (statistics.py:76-87) runs on the matrix cores through `slk_hessian_accumulate` (float32-grade
+  products of bfloat16 pieces when the feature count is a multiple of 128, float32 MFMA otherwise); the mean
   and the Hessian live on the layer's device and never visit the host.  Conv1d / Conv2d inputs are
   unfolded with `torch.nn.functional.unfold` exactly as the reference does (statistics.py:44-69) --
   data movement, not arithmetic -- and then take the same kernel.
@@ -76,9 +77,11 @@ class Sleekit:
         X = self._prepare_input(inp)
         T, n = X.shape
         assert n == self.mean.shape[0]
+        ws, ws_bytes = dev.workspace(0, n)
         _lib.check(
             _lib.lib.slk_hessian_accumulate(
-                dev.ptr(self.hessian), dev.ptr(self.mean), dev.ptr(X), n, T, int(self.count), dev.stream_handle()
+                dev.ptr(self.hessian), dev.ptr(self.mean), dev.ptr(X), n, T, int(self.count), dev.ptr(ws), ws_bytes,
+                dev.stream_handle(),
             )
         )
         self.count += T

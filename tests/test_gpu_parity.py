@@ -329,6 +329,36 @@ def test_orders_from_the_inverse_diagonal(amd, order):
         assert np.array_equal(got, want), (order, n)
 
 
+def test_hessian_accumulate_bf16_path(amd):
+    """statistics.py:76-87 with a feature count that is a multiple of 128: X^T X on the bfloat16 MFMA (three
+    pieces per operand).  A ragged token count, two batches (running-mean factor), and a workspace so small
+    that the tokens go in chunks of 32 -- each against float64, to float32 GEMM tolerance."""
+    import torch
+    from sleekit_amd import _lib, _device as dev
+
+    rng = np.random.default_rng(21)
+    n = 256
+    X1 = (rng.standard_normal((200, n)) * (0.5 + rng.random(n))).astype(np.float32)
+    X2 = (rng.standard_normal((75, n)) + 0.3).astype(np.float32)
+    want_H = (X1.astype(np.float64).T @ X1 + X2.astype(np.float64).T @ X2) / 275.0
+    want_m = (X1.astype(np.float64).sum(0) + X2.astype(np.float64).sum(0)) / 275.0
+    for ws_bytes in (None, 4096 + 6 * n * 40):  # full workspace; room for 32 tokens at a time
+        H = torch.zeros((n, n), dtype=torch.float32, device="cuda")
+        m = torch.zeros(n, dtype=torch.float32, device="cuda")
+        ws, full = dev.workspace(0, n)
+        count = 0
+        for X in (X1, X2):
+            Xd = torch.as_tensor(X, device="cuda")
+            _lib.check(_lib.lib.slk_hessian_accumulate(H.data_ptr(), m.data_ptr(), Xd.data_ptr(), n, X.shape[0], count,
+                                                       ws.data_ptr(), full if ws_bytes is None else ws_bytes, None))
+            count += X.shape[0]
+        torch.cuda.synchronize()
+        Hh = H.cpu().numpy()
+        assert np.array_equal(Hh, Hh.T)
+        np.testing.assert_allclose(Hh, want_H, rtol=2e-5, atol=2e-6 * np.abs(want_H).max())
+        np.testing.assert_allclose(m.cpu().numpy(), want_m, rtol=1e-5, atol=1e-6)
+
+
 def test_layer_error_bf16_path(amd, monkeypatch):
     """The layer error of a symmetric Hessian runs on the bfloat16 MFMA with three pieces per operand
     (six products): every row within 1e-5 of the float64 value, like the float32 kernel it replaces --

@@ -57,28 +57,28 @@ __device__ __forceinline__ void tile128_mac_planes(Acc128 &acc, TileBf16Smem &sm
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    // (Loads two rounds ahead in two register sets were tried -- a round's MFMAs last less than a trip to
-    // memory -- and were slower, 608 vs 550 us: 220 registers, and the bound is elsewhere.)
-    uint4v_t ra[3][2], rb[3][2];
+    // A round's MFMAs last ~0.7 us, less than a trip to memory: the loads run TWO rounds ahead, in two register
+    // sets used in turn.  Rounds go in pairs and every load is issued unconditionally (clamped to the last
+    // round), so that the compiler can count what is in flight (s_waitcnt vmcnt(12), not 0).
+    uint4v_t ra0[3][2], rb0[3][2], ra1[3][2], rb1[3][2];
     const int s_off = (t >> 1) * PITCH_B16 + (t & 1) * 32;
     if (k_begin >= k_end) return;
-    la(k_begin, ra);
-    lb(k_begin, rb);
+    const int k_last = k_end - KB16;
+    la(k_begin, ra0);
+    lb(k_begin, rb0);
+    la(min(k_begin + KB16, k_last), ra1);
+    lb(min(k_begin + KB16, k_last), rb1);
     const int r_off = (lane & 31) * PITCH_B16 + (lane >> 5) * 16;
-    for (int k0 = k_begin; k0 < k_end; k0 += KB16) {
-        __syncthreads();
+    auto stash = [&](const uint4v_t(&va)[3][2], const uint4v_t(&vb)[3][2]) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                *reinterpret_cast<uint4v_t *>(sm.a[p] + s_off + 16 * h) = ra[p][h];
-                *reinterpret_cast<uint4v_t *>(sm.b[p] + s_off + 16 * h) = rb[p][h];
+                *reinterpret_cast<uint4v_t *>(sm.a[p] + s_off + 16 * h) = va[p][h];
+                *reinterpret_cast<uint4v_t *>(sm.b[p] + s_off + 16 * h) = vb[p][h];
             }
-        __syncthreads();
-        if (k0 + KB16 < k_end) {
-            la(k0 + KB16, ra);
-            lb(k0 + KB16, rb);
-        }
+    };
+    auto mac = [&]() {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8_t a[2][3], b[2][3];
@@ -103,6 +103,29 @@ __device__ __forceinline__ void tile128_mac_planes(Acc128 &acc, TileBf16Smem &sm
                     acc.c[i][j] = c;
                 }
         }
+    };
+    // pairs of rounds; an odd count runs its last round once more with a zero weight?  No: every caller's depth
+    // is a multiple of 64 or ends on a pair boundary -- handled by the single-round tail below.
+    int k0 = k_begin;
+    for (; k0 + 2 * KB16 <= k_end; k0 += 2 * KB16) {
+        __syncthreads();
+        stash(ra0, rb0);
+        __syncthreads();
+        la(min(k0 + 2 * KB16, k_last), ra0);
+        lb(min(k0 + 2 * KB16, k_last), rb0);
+        mac();
+        __syncthreads();
+        stash(ra1, rb1);
+        __syncthreads();
+        la(min(k0 + 3 * KB16, k_last), ra1);
+        lb(min(k0 + 3 * KB16, k_last), rb1);
+        mac();
+    }
+    if (k0 < k_end) {  // one round left: its operands are in set 0
+        __syncthreads();
+        stash(ra0, rb0);
+        __syncthreads();
+        mac();
     }
 }
 

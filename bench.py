@@ -107,7 +107,9 @@ def main():
     backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=streams)
 
     def step():
-        shards = sdist.quantize_stream(layers, backend)
+        # join=False: consecutive steps are independent batches, so the next step's factorisations start under
+        # this step's loops (the fence below waits for everything before the clock stops)
+        shards = sdist.quantize_stream(layers, backend, join=False)
         return shards
 
     def fence():

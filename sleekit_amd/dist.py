@@ -91,8 +91,8 @@ class HipBackend:
         W, H, n = layer["W"], layer["H"], layer["H"].shape[0]
         mode = eng.order_mode_code(self.act_order)
         miss = None
-        if mode == 4:  # inv_diag / combined_diag: keys from a first factorisation
-            miss = eng.inverse_diag_keys(H, n, self.damp, eng._INVERSE_ORDERS[self.act_order])
+        if mode == 4:  # inv_diag / combined_diag / pivot: sort keys from a kernel of their own
+            miss = eng.order_keys(H, n, self.damp, self.act_order)
         elif mode >= 2:  # err / sqerr need the statistics of ALL rows, before sharding
             cb = eng.require_uniform(self.quantizer)
             Ws = eng.rows_divide(W, layer["scale"]) if layer.get("scale") is not None else W
@@ -126,7 +126,7 @@ def _all_gather_words(payload, size):
     return outs, dist.all_gather(outs, payload, async_op=True)
 
 
-def quantize_stream(layers, backend, comm_device=None):
+def quantize_stream(layers, backend, comm_device=None, join=True):
     """Quantize `layers` (list of dicts with W (R, n), H (n, n), optional scale (R,)) across the ranks.
 
     Returns, per layer, this rank's shard: dict(Q, idx, row_err, rows=(lo, hi), info).
@@ -144,6 +144,11 @@ def quantize_stream(layers, backend, comm_device=None):
       comm stream    : pack + all-gather of each round, behind that round's factor event
       loop streams   : the row loops, each behind its round's collective
     so the factorisation of round g+1 runs under the loops and errors of round g.
+
+    `join` (default): the caller's stream waits for the loop streams before this returns, so the results can
+    be used on it at once.  With join=False nothing waits: the NEXT call's factorisations then start under
+    this call's loops (a throughput loop over independent batches, bench.py) -- synchronise the device, or
+    the loop streams, before reading the results.
     """
     rank, size = world()
     n_layers = len(layers)
@@ -185,6 +190,9 @@ def quantize_stream(layers, backend, comm_device=None):
                     if ready[l] is not None:
                         cstream.wait_event(ready[l])
                     payload = backend.pack(factors[l], words)
+                    if side:
+                        for t in factors[l]:
+                            t.record_stream(cstream)  # made on a factor stream, read here
                 else:  # no layer for this rank in the last round: contribute a blank
                     dev_ = comm_device if comm_device is not None else layers[0]["H"].device
                     payload = backend.alloc_payload(words, dev_).zero_()
@@ -207,11 +215,18 @@ def quantize_stream(layers, backend, comm_device=None):
                 ls.wait_event(ready[l])
             lo, hi = row_range(layer["W"].shape[0], rank, size)
             shard = backend.run_rows(layer, lo, hi, factors[l])
+            if side:  # made on a factor / comm stream, read on this one
+                for t in factors[l]:
+                    t.record_stream(ls)
+                if size > 1:
+                    for t in gathered[l // size][0]:
+                        t.record_stream(ls)
         shard["info"] = factors[l][2]
         out.append(shard)
     if side:
-        for st in lstreams:
-            here.wait_stream(st)
+        if join:
+            for st in lstreams:
+                here.wait_stream(st)
         # tensors made on the side streams are consumed on the caller's stream: keep the allocator honest
         extra = [(p,) for p in keep] + [tuple(g[0]) for g in gathered if g is not None]
         for f in factors + extra:

@@ -39,6 +39,12 @@ struct OpTable {
 };
 
 // ------------------------------------------------------------------ permute in / out
+// Both are row gathers by a fixed column permutation.  A row goes through LDS: coalesced 16-byte loads in,
+// the gather reads LDS (random 4-byte reads there cost a few cycles; straight from global every one of them
+// was its own L1/L2 request: 2 TB/s), coalesced 16-byte stores out.  Rows longer than PERM_MAX floats take
+// the plain kernels.
+constexpr int PERM_MAX = 16384;
+
 // Qp[r][c] = W[r][order[c]] (/ scale[r]);  E is cleared by the window kernels as they go.
 __global__ __launch_bounds__(256) void k_permute_in(const float *__restrict__ W, const float *__restrict__ scale,
                                                     const long long *__restrict__ order, int R, int n,
@@ -56,6 +62,31 @@ __global__ __launch_bounds__(256) void k_permute_in(const float *__restrict__ W,
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < n; c += blockDim.x) inv_order[order ? order[c] : c] = c;
 }
+__global__ __launch_bounds__(256) void k_permute_in_lds(const float *__restrict__ W, const float *__restrict__ scale,
+                                                        const long long *__restrict__ order, int R, int n,
+                                                        float *__restrict__ Qp, int *__restrict__ inv_order) {
+    extern __shared__ __attribute__((aligned(16))) float row[];
+    const int t = threadIdx.x, n4 = n >> 2;
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        const float4v_t *src = reinterpret_cast<const float4v_t *>(W + (size_t)r * n);
+        __syncthreads();  // the previous row's gathers are done
+        for (int c = t; c < n4; c += 256) reinterpret_cast<float4v_t *>(row)[c] = src[c];
+        __syncthreads();
+        const float s = scale ? scale[r] : 1.0f;
+        float4v_t *dst = reinterpret_cast<float4v_t *>(Qp + (size_t)r * n);
+        for (int c = t; c < n4; c += 256) {
+            float4v_t v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = row[order[4 * c + e]];
+                v[e] = scale ? x / s : x;
+            }
+            dst[c] = v;
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int c = t; c < n; c += 256) inv_order[order[c]] = c;
+}
 
 // Q[r][j] = Qp[r][inv[j]];  idx[r][j] = grid index of that value (codebook.py:43-54).
 __global__ __launch_bounds__(256) void k_permute_out(const float *__restrict__ Qp, const int *__restrict__ inv_order,
@@ -67,6 +98,31 @@ __global__ __launch_bounds__(256) void k_permute_out(const float *__restrict__ Q
             const float v = src[inv_order[j]];
             Q[(size_t)r * n + j] = v;
             if (idx) idx[(size_t)r * n + j] = (uint8_t)cb_index(v, g);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_permute_out_lds(const float *__restrict__ Qp, const int *__restrict__ inv_order,
+                                                         int R, int n, Grid g, float *__restrict__ Q,
+                                                         uint8_t *__restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) float row[];
+    const int t = threadIdx.x, n4 = n >> 2;
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        const float4v_t *src = reinterpret_cast<const float4v_t *>(Qp + (size_t)r * n);
+        __syncthreads();
+        for (int c = t; c < n4; c += 256) reinterpret_cast<float4v_t *>(row)[c] = src[c];
+        __syncthreads();
+        float4v_t *dst = reinterpret_cast<float4v_t *>(Q + (size_t)r * n);
+        unsigned *di = idx ? reinterpret_cast<unsigned *>(idx + (size_t)r * n) : nullptr;
+        for (int c = t; c < n4; c += 256) {
+            float4v_t v;
+            unsigned packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = row[inv_order[4 * c + e]];
+                if (idx) packed |= (unsigned)(cb_index(v[e], g) & 255) << (8 * e);
+            }
+            dst[c] = v;
+            if (idx) di[c] = packed;
         }
     }
 }
@@ -796,7 +852,19 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
     }
     const bool periods_ok = n % 2 == 0 && (uintptr_t)U % 16 == 0 && getenv("SLK_NO_WINDOW2") == nullptr && (dbg & ~24) == 0;
 
-    SLK_RUN("permute_in", 0, 8.0 * R * n, s, k_permute_in<<<R < 2048 ? R : 2048, 256, 0, s>>>(W, scale, order, R, n, Qp, inv_order));
+    // rows staged through LDS when they fit and 16-byte accesses line up
+    const bool perm_lds = order && n % 4 == 0 && n <= PERM_MAX && ((uintptr_t)W | (uintptr_t)Q | (uintptr_t)workspace) % 16 == 0 &&
+                          (idx == nullptr || (uintptr_t)idx % 4 == 0);
+    static bool perm_attr = false;
+    if (perm_lds && !perm_attr) {
+        SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permute_in_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PERM_MAX * 4));
+        SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permute_out_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PERM_MAX * 4));
+        perm_attr = true;
+    }
+    if (perm_lds)
+        SLK_RUN("permute_in", 0, 8.0 * R * n, s, k_permute_in_lds<<<R < 2048 ? R : 2048, 256, (size_t)n * 4, s>>>(W, scale, order, R, n, Qp, inv_order));
+    else
+        SLK_RUN("permute_in", 0, 8.0 * R * n, s, k_permute_in<<<R < 2048 ? R : 2048, 256, 0, s>>>(W, scale, order, R, n, Qp, inv_order));
 
     Plan p;
     plan(0, n, min_block, num_blocks, p);
@@ -864,7 +932,10 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
             }
         }
     }
-    SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, Q, idx));
+    if (perm_lds)
+        SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out_lds<<<R < 2048 ? R : 2048, 256, (size_t)n * 4, s>>>(Qp, inv_order, R, n, g, Q, idx));
+    else
+        SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, Q, idx));
     if (E_out) SLK_HIP(hipMemcpyAsync(E_out, Eg, sizeof(float) * (size_t)R * n, hipMemcpyDeviceToDevice, s));
     return SLK_OK;
 }

@@ -5,6 +5,8 @@
 
 namespace slk {
 
+typedef float float4v_t __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------ diag mean
 // mean(diag H) in float32 with NumPy's summation order (npsum.h): feeds the damping term.
 __global__ __launch_bounds__(256) void k_diag_mean(const float *__restrict__ H, int n, int ld,
@@ -90,6 +92,38 @@ __global__ __launch_bounds__(256) void k_gather_reversed(const float *__restrict
             double v = 0.0;
             if (j <= i) {
                 v = (double)src[order[n - 1 - j]];
+                if (j == i) v = v + add;
+            }
+            row[j] = v;
+        }
+    }
+}
+
+// The same through LDS: the source row is loaded once with coalesced 16-byte loads and gathered there (random
+// 4-byte reads straight from global were one L1/L2 request each), and the tiles strictly above the diagonal,
+// which no kernel of the factorisation reads, are not written at all (the 64 x 64 diagonal tiles are kept whole:
+// the trailing update reads and rewrites them entirely).  n % 4 == 0, n <= 16384.
+__global__ __launch_bounds__(256) void k_gather_reversed_lds(const float *__restrict__ H, int n, int ld,
+                                                             const long long *__restrict__ order,
+                                                             const float *__restrict__ scal, double *__restrict__ A) {
+    extern __shared__ __attribute__((aligned(16))) float srow[];
+    const double add = (double)scal[1];
+    const int t = threadIdx.x, n4 = n >> 2;
+    for (int i = blockIdx.x; i < ld; i += gridDim.x) {
+        double *row = A + (size_t)i * ld;
+        const int stop = min(ld, (i / 64 + 1) * 64);  // end of the diagonal tile
+        if (i >= n) {
+            for (int j = t; j < stop; j += 256) row[j] = (i == j) ? 1.0 : 0.0;
+            continue;
+        }
+        const float4v_t *src = reinterpret_cast<const float4v_t *>(H + (size_t)order[n - 1 - i] * n);
+        __syncthreads();
+        for (int c = t; c < n4; c += 256) reinterpret_cast<float4v_t *>(srow)[c] = src[c];
+        __syncthreads();
+        for (int j = t; j < stop; j += 256) {
+            double v = 0.0;
+            if (j <= i) {
+                v = (double)srow[order[n - 1 - j]];
                 if (j == i) v = v + add;
             }
             row[j] = v;
@@ -354,8 +388,18 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
         SLK_RUN("rank_partial", 0, 16.0 * n, s, k_rank_partial<<<dim3((n + 255) / 256, slices), 256, 0, s>>>(keys, n, slice, rank));
     }
     SLK_RUN("rank_scatter", 0, 12.0 * n, s, k_rank_scatter<<<(n + 255) / 256, 256, 0, s>>>(rank, n, identity, order_out));
-    SLK_RUN("gather_reversed", 0, 2.0 * n * n + 8.0 * ld * ld, s,
-            k_gather_reversed<<<ld < 2048 ? ld : 2048, 256, 0, s>>>(H, n, ld, order_out, scal, A));
+    if (n % 4 == 0 && n <= 16384 && (uintptr_t)H % 16 == 0) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather_reversed_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
+            attr_set = true;
+        }
+        SLK_RUN("gather_reversed", 0, 4.0 * n * n + 4.0 * ld * ld, s,
+                k_gather_reversed_lds<<<ld < 2048 ? ld : 2048, 256, (size_t)n * 4, s>>>(H, n, ld, order_out, scal, A));
+    } else {
+        SLK_RUN("gather_reversed", 0, 2.0 * n * n + 8.0 * ld * ld, s,
+                k_gather_reversed<<<ld < 2048 ? ld : 2048, 256, 0, s>>>(H, n, ld, order_out, scal, A));
+    }
     return SLK_OK;
 }
 

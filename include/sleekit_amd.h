@@ -147,13 +147,14 @@ int slk_factor_unpack(const void *payload, int n, double *U, long long *order, i
  *     the reference's recursion (min_block, num_blocks), float64 updates rounded to
  *     float32 at the reference's rounding points.
  *     order (may be NULL): identity, i.e. _quantize_opt_block on Q as given (obq.py:121-137).
- *     Q (R x n float32, original column order): codebook VALUES in the scaled domain.
+ *     Q (R x n float32, original column order): codebook VALUES in the scaled domain, or -- unscale != 0,
+ *       scale given -- de-scaled like quantize_with_scaling's result (scaling.py:80: q / (1 / scale[r])).
  *     idx (may be NULL): codebook indices, uint8, original column order.
  *     E_out (may be NULL): the scaled errors E of obq.py:115, R x n, in PROCESSING order. */
 int slk_gptq_quantize(const float *W, const float *scale, const long long *order, const double *U,
                       int R, int n, int levels, double lo, double hi, const float *table, int min_block,
-                      int num_blocks, float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
-                      slk_stream_t stream);
+                      int num_blocks, int unscale, float *Q, uint8_t *idx, float *E_out, void *workspace,
+                      size_t ws_bytes, slk_stream_t stream);
 
 /* a11 channelwise_error  (sleekit/obq.py:89-95): row_err[r] = (W-Q)[r] H (W-Q)[r]^T.
  *     G (may be NULL): the R x n product (W - Q) @ H, reused by the local search. */

@@ -49,7 +49,7 @@ PROTOTYPES = {
     "slk_factor_unpack": (c_int, [P, c_int, P, P, P, P]),
     "slk_gptq_quantize": (
         c_int,
-        [P, P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, c_int, P, P, P, P, c_size_t, P],
+        [P, P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P],
     ),
     "slk_row_errors": (c_int, [P, P, P, c_int, c_int, P, P, P, c_size_t, P]),
     "slk_local_search": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P, c_size_t, P]),

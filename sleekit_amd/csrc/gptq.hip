@@ -90,20 +90,21 @@ __global__ __launch_bounds__(256) void k_permute_in_lds(const float *__restrict_
 
 // Q[r][j] = Qp[r][inv[j]];  idx[r][j] = grid index of that value (codebook.py:43-54).
 __global__ __launch_bounds__(256) void k_permute_out(const float *__restrict__ Qp, const int *__restrict__ inv_order,
-                                                     int R, int n, Grid g, float *__restrict__ Q,
-                                                     uint8_t *__restrict__ idx) {
+                                                     int R, int n, Grid g, const float *__restrict__ unscale,
+                                                     float *__restrict__ Q, uint8_t *__restrict__ idx) {
     for (int r = blockIdx.x; r < R; r += gridDim.x) {
         const float *src = Qp + (size_t)r * n;
+        const float inv = unscale ? 1.0f / unscale[r] : 1.0f;  // scaling.py:80: a division by the reciprocal
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
             const float v = src[inv_order[j]];
-            Q[(size_t)r * n + j] = v;
+            Q[(size_t)r * n + j] = unscale ? v / inv : v;
             if (idx) idx[(size_t)r * n + j] = (uint8_t)cb_index(v, g);
         }
     }
 }
 __global__ __launch_bounds__(256) void k_permute_out_lds(const float *__restrict__ Qp, const int *__restrict__ inv_order,
-                                                         int R, int n, Grid g, float *__restrict__ Q,
-                                                         uint8_t *__restrict__ idx) {
+                                                         int R, int n, Grid g, const float *__restrict__ unscale,
+                                                         float *__restrict__ Q, uint8_t *__restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) float row[];
     const int t = threadIdx.x, n4 = n >> 2;
     for (int r = blockIdx.x; r < R; r += gridDim.x) {
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256) void k_permute_out_lds(const float *__restrict
         __syncthreads();
         float4v_t *dst = reinterpret_cast<float4v_t *>(Q + (size_t)r * n);
         unsigned *di = idx ? reinterpret_cast<unsigned *>(idx + (size_t)r * n) : nullptr;
+        const float inv = unscale ? 1.0f / unscale[r] : 1.0f;  // scaling.py:80: a division by the reciprocal
         for (int c = t; c < n4; c += 256) {
             float4v_t v;
             unsigned packed = 0;
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256) void k_permute_out_lds(const float *__restrict
             for (int e = 0; e < 4; ++e) {
                 v[e] = row[inv_order[4 * c + e]];
                 if (idx) packed |= (unsigned)(cb_index(v[e], g) & 255) << (8 * e);
+                if (unscale) v[e] = v[e] / inv;
             }
             dst[c] = v;
             if (idx) di[c] = packed;
@@ -816,9 +819,10 @@ extern "C" int slk_probe_window_cycles(long long *host_out, int reset) {
 
 extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long long *order, const double *U,
                                  int R, int n, int levels, double lo, double hi, const float *table, int min_block, int num_blocks,
-                                 float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
+                                 int unscale, float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
                                  slk_stream_t stream) {
     SLK_REQUIRE(W && U && Q, "null pointer");
+    SLK_REQUIRE(!unscale || scale, "unscale needs the row scales");
     SLK_REQUIRE(R > 0 && n > 0, "empty layer");
     SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
     SLK_REQUIRE(table == nullptr || levels <= 256, "general codebooks hold at most 256 entries");
@@ -933,9 +937,9 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
         }
     }
     if (perm_lds)
-        SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out_lds<<<R < 2048 ? R : 2048, 256, (size_t)n * 4, s>>>(Qp, inv_order, R, n, g, Q, idx));
+        SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out_lds<<<R < 2048 ? R : 2048, 256, (size_t)n * 4, s>>>(Qp, inv_order, R, n, g, unscale ? scale : nullptr, Q, idx));
     else
-        SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, Q, idx));
+        SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, unscale ? scale : nullptr, Q, idx));
     if (E_out) SLK_HIP(hipMemcpyAsync(E_out, Eg, sizeof(float) * (size_t)R * n, hipMemcpyDeviceToDevice, s));
     return SLK_OK;
 }

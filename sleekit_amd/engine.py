@@ -111,8 +111,8 @@ def factorize_order_only(H, n, mode, miss=None):
     return order, None, None
 
 
-def run_loop(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=True, want_E=False):
-    """The column-sequential loop on device tensors. Returns (Q, idx, E)."""
+def run_loop(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=True, want_E=False, unscale=False):
+    """The column-sequential loop on device tensors. Returns (Q, idx, E); `unscale`: Q comes back de-scaled."""
     R, n = W.shape
     levels, lo, hi, table = cb_abi
     ws, ws_bytes = dev.workspace(R, n)
@@ -122,7 +122,8 @@ def run_loop(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=True, w
     _lib.check(
         _lib.lib.slk_gptq_quantize(
             dev.ptr(W), dev.ptr(scale), dev.ptr(order), dev.ptr(U), R, n, levels, lo, hi, dev.ptr(table), int(min_block),
-            int(num_blocks), dev.ptr(Q), dev.ptr(idx), dev.ptr(E), dev.ptr(ws), ws_bytes, dev.stream_handle(),
+            int(num_blocks), 1 if unscale else 0, dev.ptr(Q), dev.ptr(idx), dev.ptr(E), dev.ptr(ws), ws_bytes,
+            dev.stream_handle(),
         )
     )
     return Q, idx, E
@@ -209,9 +210,11 @@ def quantize_layer(
         dev.note_info(factor[2], "compute_hessian_chol")
     res.order, res.U, res.info = factor
 
-    res.Q, res.idx, _ = run_loop(Ws, loop_scale, res.order, res.U, cb_abi, min_block_size, num_blocks, want_idx)
+    # without local search the loop's last kernel de-scales on the way out (one pass over Q less)
+    fused = scale is not None and unscale and nb_ls_moves == 0 and loop_scale is not None
+    res.Q, res.idx, _ = run_loop(Ws, loop_scale, res.order, res.U, cb_abi, min_block_size, num_blocks, want_idx, unscale=fused)
     if nb_ls_moves > 0:
         local_search(Ws, res.Q, H, cb_abi, nb_ls_moves, res.idx)
-    if scale is not None and unscale:
+    if scale is not None and unscale and not fused:
         res.Q = rows_divide(res.Q, scale, invert=True)
     return res

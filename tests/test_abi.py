@@ -47,7 +47,7 @@ def test_argument_errors_do_not_touch_the_gpu():
 
     assert _lib.lib.slk_codebook_apply(None, 4, 1, -1.0, 1.0, None, 0, None, None) == _lib.E_ARG
     assert b"levels" in _lib.lib.slk_last_error()
-    assert _lib.lib.slk_gptq_quantize(None, None, None, None, 4, 4, 8, -1.0, 1.0, None, 32, 8, None, None, None, None, 0, None) == _lib.E_ARG
+    assert _lib.lib.slk_gptq_quantize(None, None, None, None, 4, 4, 8, -1.0, 1.0, None, 32, 8, 0, None, None, None, None, 0, None) == _lib.E_ARG
     assert _lib.lib.slk_hessian_prepare(None, 0, 0.01, 1, None, None, None, None, 0, None) == _lib.E_ARG
     with pytest.raises(RuntimeError):
         _lib.check(_lib.E_ARG)

@@ -359,6 +359,27 @@ def test_hessian_accumulate_bf16_path(amd):
         np.testing.assert_allclose(m.cpu().numpy(), want_m, rtol=1e-5, atol=1e-6)
 
 
+def test_integration_stub_runs(amd):
+    """The ctypes binding printed in INTEGRATION.md is executed as it stands (library path aside) and must
+    give what sleekit_amd.obq.quantize_opt gives."""
+    import os
+    import re
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = next(b for b in re.findall(r"```python\n(.*?)```", text, re.S) if "quantize_opt_mi355x" in b)
+    code = "\n".join(line[3:] if line.startswith("   ") else line for line in code.splitlines())
+    code = code.replace('ctypes.CDLL("libsleekit_amd.so")', f'ctypes.CDLL("{os.path.join(root, "sleekit_amd", "libsleekit_amd.so")}")')
+    ns = {"numpy": np}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    L = layer(64, 96, 2001)
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    Ws = scaling_ref.divide_rows(L["W"], L["scale"], 0)
+    got = ns["quantize_opt_mi355x"](torch.from_numpy(Ws).cuda(), torch.from_numpy(L["H"]).cuda(), cb)
+    assert np.array_equal(got.cpu().numpy(), amd.obq.quantize_opt(Ws, L["H"], cb))
+
+
 def test_layer_error_bf16_path(amd, monkeypatch):
     """The layer error of a symmetric Hessian runs on the bfloat16 MFMA with three pieces per operand
     (six products): every row within 1e-5 of the float64 value, like the float32 kernel it replaces --

@@ -20,6 +20,11 @@ import torch
 import torch.distributed as dist
 
 
+# Test hook: exchange (pack, all-gather, unpack) even on a single rank, so that a one-GPU box can drive the
+# RCCL path end to end (tests/test_gpu_parity.py::test_exchange_over_rccl_single_rank).
+always_exchange = False
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -158,6 +163,7 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
     fstreams, cstream, lstreams = backend.streams() if hasattr(backend, "streams") else (None, None, None)
     side = fstreams is not None
     here = torch.cuda.current_stream() if side else None
+    exchange = size > 1 or always_exchange
 
     def on(stream):
         return torch.cuda.stream(stream) if stream is not None else _NullCtx()
@@ -177,7 +183,7 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
     # 2. one asynchronous all-gather per round, issued in round order
     gathered = [None] * n_rounds  # (per-rank payloads, work)
     keep = []
-    if size > 1:
+    if exchange:
         if cstream is not None:
             cstream.wait_stream(here)
         with on(cstream):
@@ -206,10 +212,10 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
         if side and l < len(lstreams):
             ls.wait_stream(here)
         with on(ls):
-            if size > 1:
+            if exchange:
                 parts, work = gathered[l // size]
                 work.wait()  # orders the stream behind the transfer; no host block on GPU
-                if factors[l] is None:
+                if factors[l] is None or always_exchange:
                     factors[l] = backend.unpack(parts[l % size], layer["H"].shape[0])
             elif ready[l] is not None:
                 ls.wait_event(ready[l])
@@ -218,7 +224,7 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
             if side:  # made on a factor / comm stream, read on this one
                 for t in factors[l]:
                     t.record_stream(ls)
-                if size > 1:
+                if exchange:
                     for t in gathered[l // size][0]:
                         t.record_stream(ls)
         shard["info"] = factors[l][2]

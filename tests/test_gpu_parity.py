@@ -6,6 +6,7 @@ need not match LAPACK bit-wise: SURVEY.md 8a6); layer errors to 1e-5 relative (n
 """
 
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -668,3 +669,14 @@ def test_headline_properties_4096(amd):
     # (4) GPTQ beats round-to-nearest
     rtn = amd.scaling.quantize_with_scaling(W, sc, cb)
     assert e_full < float(amd.obq.quantization_error(W, rtn, H))
+
+
+def test_exchange_over_rccl_single_rank():
+    """The N > 1 exchange (pack, RCCL all-gather on the comm stream, unpack) driven on this one GPU."""
+    import subprocess
+    import sys
+
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_single_rank.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, script, "29643"], capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0 and "RCCL_SINGLE_RANK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

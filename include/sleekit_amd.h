@@ -156,10 +156,27 @@ int slk_gptq_quantize(const float *W, const float *scale, const long long *order
                       int num_blocks, int unscale, float *Q, uint8_t *idx, float *E_out, void *workspace,
                       size_t ws_bytes, slk_stream_t stream);
 
+/* (e) The same loop over `batch` layers of one shape at once, stacked by rows: W, Q, idx, E_out are
+ *     (batch * rows_per_layer) x n, scale has batch * rows_per_layer entries, order is batch x n and U is
+ *     batch x n x n (layer b's rows use order[b], U[b]).  Results are those of `batch` separate calls, bit for
+ *     bit -- rows never interact (obq.py:106-137) -- but every launch covers all the layers: the row shards of
+ *     a multi-GPU run (R / G rows each) fill the chip together where each alone leaves most of it
+ *     idle.  batch in 1..64; batch > 1 needs rows_per_layer % 64 == 0 and the orders.
+ *     Workspace: slk_workspace_bytes_batch(batch, rows_per_layer, n).                                       */
+int slk_gptq_quantize_batch(const float *W, const float *scale, const long long *order, const double *U,
+                            int batch, int rows_per_layer, int n, int levels, double lo, double hi,
+                            const float *table, int min_block, int num_blocks, int unscale, float *Q,
+                            uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes, slk_stream_t stream);
+size_t slk_workspace_bytes_batch(int batch, int rows_per_layer, int n);
+
 /* a11 channelwise_error  (sleekit/obq.py:89-95): row_err[r] = (W-Q)[r] H (W-Q)[r]^T.
  *     G (may be NULL): the R x n product (W - Q) @ H, reused by the local search. */
 int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n, float *row_err,
                    float *G, void *workspace, size_t ws_bytes, slk_stream_t stream);
+/*     ... of `batch` layers stacked by rows (see slk_gptq_quantize_batch): H is a HOST array of `batch` device
+ *     pointers, one n x n Hessian each; batch > 1 needs rows_per_layer % 128 == 0.                          */
+int slk_row_errors_batch(const float *W, const float *Q, const float *const *H, int batch, int rows_per_layer,
+                         int n, float *row_err, void *workspace, size_t ws_bytes, slk_stream_t stream);
 
 /* a12+a13 quantize_local_search  (sleekit/obq.py:220-358)
  *     W, Q: R x n float32 in the scaled domain; Q is updated in place, idx

@@ -57,10 +57,13 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-def workspace(R, n):
-    """(tensor, bytes): grow-only scratch per (device, stream) sized by slk_workspace_bytes."""
+def workspace(R, n, batch=1):
+    """(tensor, bytes): grow-only scratch per (device, stream) sized by slk_workspace_bytes(_batch)."""
     dev = require_gpu()
-    need = int(_lib.lib.slk_workspace_bytes(int(R), int(n)))
+    if batch > 1:
+        need = int(_lib.lib.slk_workspace_bytes_batch(int(batch), int(R), int(n)))
+    else:
+        need = int(_lib.lib.slk_workspace_bytes(int(R), int(n)))
     key = (dev.index, stream_handle())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:

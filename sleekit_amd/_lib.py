@@ -51,7 +51,13 @@ PROTOTYPES = {
         c_int,
         [P, P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P],
     ),
+    "slk_gptq_quantize_batch": (
+        c_int,
+        [P, P, P, P, c_int, c_int, c_int, c_int, c_double, c_double, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P],
+    ),
+    "slk_workspace_bytes_batch": (c_size_t, [c_int, c_int, c_int]),
     "slk_row_errors": (c_int, [P, P, P, c_int, c_int, P, P, P, c_size_t, P]),
+    "slk_row_errors_batch": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_size_t, P]),
     "slk_local_search": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P, c_size_t, P]),
     "slk_scale_minmax": (c_int, [P, c_int, c_int, c_double, c_double, P, P]),
     "slk_scale_norm": (c_int, [P, c_int, c_int, P, P]),

@@ -116,7 +116,7 @@ size_t slk_workspace_bytes(int R, int n) {
     size_t loop = 2 * rn * sizeof(float) + (size_t)n * sizeof(int);    // permuted Q and E, inverse order
     size_t search = rn * sizeof(float) + (size_t)(R + n) * sizeof(float) + (size_t)R * ((n + 127) / 128) * sizeof(float) + 4096;
     // layer error on the bfloat16 MFMA: three 2-byte planes of W - Q and of H, the per-tile partial sums
-    size_t error = 6 * (rn + 128 * (size_t)n) + 6 * (size_t)n * n + (size_t)R * ((n + 127) / 128) * sizeof(float) + 8192;
+    size_t error = 6 * (rn + 128 * (size_t)n) + 6 * (size_t)n * n + 4 * (size_t)R * ((n + 127) / 128) * sizeof(float) + 8192;
     size_t prep = 64 * sizeof(float) + (size_t)n * (sizeof(double) + 1);
     size_t m = factor;
     if (loop > m) m = loop;
@@ -124,6 +124,13 @@ size_t slk_workspace_bytes(int R, int n) {
     if (error > m) m = error;
     if (prep > m) m = prep;
     return m + (1u << 16);
+}
+
+size_t slk_workspace_bytes_batch(int batch, int rows_per_layer, int n) {
+    if (batch < 1 || batch > 64 || rows_per_layer < 0 || n <= 0 || (long long)batch * rows_per_layer > 0x7fffffffLL) return 0;
+    // the stacked rows as one layer, plus the operand planes of the other Hessians and the other inverse orders
+    return slk_workspace_bytes(batch * rows_per_layer, n) + (size_t)(batch - 1) * 6 * (size_t)n * n +
+           (size_t)batch * n * sizeof(int) + 4096;
 }
 
 int slk_probe_mfma_f64(double *sink, int blocks, int iters, slk_stream_t stream) {

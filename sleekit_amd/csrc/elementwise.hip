@@ -112,7 +112,7 @@ using namespace slk;
 
 extern "C" {
 
-int slk_abi_version(void) { return 2; }
+int slk_abi_version(void) { return 3; }
 
 const char *slk_last_error(void) { return g_error; }
 

@@ -48,26 +48,30 @@ constexpr int PERM_MAX = 16384;
 // Qp[r][c] = W[r][order[c]] (/ scale[r]);  E is cleared by the window kernels as they go.
 __global__ __launch_bounds__(256) void k_permute_in(const float *__restrict__ W, const float *__restrict__ scale,
                                                     const long long *__restrict__ order, int R, int n,
-                                                    float *__restrict__ Qp, int *__restrict__ inv_order) {
+                                                    float *__restrict__ Qp, int *__restrict__ inv_order, int rpl) {
+    // (a batch of layers stacked by rows: rows [b rpl, (b + 1) rpl) follow order[b], inv_order[b])
     for (int r = blockIdx.x; r < R; r += gridDim.x) {
         const float *src = W + (size_t)r * n;
         float *dst = Qp + (size_t)r * n;
+        const long long *ord = order ? order + (size_t)(r / rpl) * n : nullptr;
         if (scale) {
             const float s = scale[r];
-            for (int c = threadIdx.x; c < n; c += blockDim.x) dst[c] = src[order ? order[c] : c] / s;
+            for (int c = threadIdx.x; c < n; c += blockDim.x) dst[c] = src[ord ? ord[c] : c] / s;
         } else {
-            for (int c = threadIdx.x; c < n; c += blockDim.x) dst[c] = src[order ? order[c] : c];
+            for (int c = threadIdx.x; c < n; c += blockDim.x) dst[c] = src[ord ? ord[c] : c];
         }
     }
-    if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < n; c += blockDim.x) inv_order[order ? order[c] : c] = c;
+    for (int b = blockIdx.x; b < (R + rpl - 1) / rpl; b += gridDim.x)
+        for (int c = threadIdx.x; c < n; c += blockDim.x) inv_order[(size_t)b * n + (order ? order[(size_t)b * n + c] : c)] = c;
 }
 __global__ __launch_bounds__(256) void k_permute_in_lds(const float *__restrict__ W, const float *__restrict__ scale,
                                                         const long long *__restrict__ order, int R, int n,
-                                                        float *__restrict__ Qp, int *__restrict__ inv_order) {
+                                                        float *__restrict__ Qp, int *__restrict__ inv_order, int rpl) {
     extern __shared__ __attribute__((aligned(16))) float row[];
     const int t = threadIdx.x, n4 = n >> 2;
+    const long long *order_all = order;
     for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        order = order_all + (size_t)(r / rpl) * n;
         const float4v_t *src = reinterpret_cast<const float4v_t *>(W + (size_t)r * n);
         __syncthreads();  // the previous row's gathers are done
         for (int c = t; c < n4; c += 256) reinterpret_cast<float4v_t *>(row)[c] = src[c];
@@ -84,19 +88,20 @@ __global__ __launch_bounds__(256) void k_permute_in_lds(const float *__restrict_
             dst[c] = v;
         }
     }
-    if (blockIdx.x == 0)
-        for (int c = t; c < n; c += 256) inv_order[order[c]] = c;
+    for (int b = blockIdx.x; b < (R + rpl - 1) / rpl; b += gridDim.x)
+        for (int c = t; c < n; c += 256) inv_order[(size_t)b * n + order_all[(size_t)b * n + c]] = c;
 }
 
 // Q[r][j] = Qp[r][inv[j]];  idx[r][j] = grid index of that value (codebook.py:43-54).
 __global__ __launch_bounds__(256) void k_permute_out(const float *__restrict__ Qp, const int *__restrict__ inv_order,
                                                      int R, int n, Grid g, const float *__restrict__ unscale,
-                                                     float *__restrict__ Q, uint8_t *__restrict__ idx) {
+                                                     float *__restrict__ Q, uint8_t *__restrict__ idx, int rpl) {
     for (int r = blockIdx.x; r < R; r += gridDim.x) {
         const float *src = Qp + (size_t)r * n;
+        const int *inv_o = inv_order + (size_t)(r / rpl) * n;
         const float inv = unscale ? 1.0f / unscale[r] : 1.0f;  // scaling.py:80: a division by the reciprocal
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
-            const float v = src[inv_order[j]];
+            const float v = src[inv_o[j]];
             Q[(size_t)r * n + j] = unscale ? v / inv : v;
             if (idx) idx[(size_t)r * n + j] = (uint8_t)cb_index(v, g);
         }
@@ -104,10 +109,12 @@ __global__ __launch_bounds__(256) void k_permute_out(const float *__restrict__ Q
 }
 __global__ __launch_bounds__(256) void k_permute_out_lds(const float *__restrict__ Qp, const int *__restrict__ inv_order,
                                                          int R, int n, Grid g, const float *__restrict__ unscale,
-                                                         float *__restrict__ Q, uint8_t *__restrict__ idx) {
+                                                         float *__restrict__ Q, uint8_t *__restrict__ idx, int rpl) {
     extern __shared__ __attribute__((aligned(16))) float row[];
     const int t = threadIdx.x, n4 = n >> 2;
+    const int *inv_all = inv_order;
     for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        inv_order = inv_all + (size_t)(r / rpl) * n;
         const float4v_t *src = reinterpret_cast<const float4v_t *>(Qp + (size_t)r * n);
         __syncthreads();
         for (int c = t; c < n4; c += 256) reinterpret_cast<float4v_t *>(row)[c] = src[c];
@@ -258,13 +265,14 @@ __device__ long long g_win_trace[64];  // window2: busy cycles per period, chain
 template <bool IN_LDS>
 __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, float *__restrict__ Eg,
                                                      const double *__restrict__ U, int R, int n, int w0, int w1,
-                                                     Grid g, float inv_step, int fast_ok, int dbg, OpTable tab) {
+                                                     Grid g, float inv_step, int fast_ok, int dbg, OpTable tab, int rpl) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     WindowSmem &sm = *reinterpret_cast<WindowSmem *>(smem_raw);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool helper = wave >= 4;
     const int ht = t - 256;  // helper thread index
     const int r0 = blockIdx.x * RB;
+    U += (size_t)(r0 / rpl) * n * n;  // a batch of layers stacked by rows: rows [b rpl, (b + 1) rpl) use factor b
     if (IN_LDS && g.table) {  // the leaves search the codebook once per column: keep it next to them
         for (int i = t; i < 2 * g.n - 1; i += 512) sm.cbt[i] = g.table[i];
         g.table = sm.cbt;  // visible after the first barrier below
@@ -633,9 +641,10 @@ namespace slk {
 // Qp[:, ja:jb] = float32(float64(Qp[:, ja:jb]) - E[:, ka:kb] @ U[ka:kb, ja:jb]), 64 x 64 tiles.
 __global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, const float *__restrict__ Eg,
                                                        const double *__restrict__ U, int R, int n, int ka, int kb,
-                                                       int ja, int jb, int vec_ok) {
+                                                       int ja, int jb, int vec_ok, int rpl) {
     __shared__ __attribute__((aligned(16))) Tile64Smem sm;
     const int r0 = blockIdx.y * TILE, j0 = ja + blockIdx.x * TILE;
+    U += (size_t)(r0 / rpl) * n * n;  // batch of layers stacked by rows (rpl a multiple of the tile)
     const int t = threadIdx.x;
     Acc64 acc;
     acc.zero();
@@ -821,9 +830,25 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
                                  int R, int n, int levels, double lo, double hi, const float *table, int min_block, int num_blocks,
                                  int unscale, float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
                                  slk_stream_t stream) {
+    return slk_gptq_quantize_batch(W, scale, order, U, 1, R, n, levels, lo, hi, table, min_block, num_blocks, unscale, Q, idx,
+                                   E_out, workspace, ws_bytes, stream);
+}
+
+// `batch` layers of one shape stacked by rows: every launch of the loop covers all of them, each row tile
+// reading its own layer's factor.  What a row shard of a multi-GPU run needs: R / G rows alone leave most of
+// the chip idle (the window kernel runs one workgroup per 16 rows), G layers' shards together fill it.
+extern "C" int slk_gptq_quantize_batch(const float *W, const float *scale, const long long *order, const double *U,
+                                       int batch, int rows_per_layer, int n, int levels, double lo, double hi,
+                                       const float *table, int min_block, int num_blocks, int unscale, float *Q, uint8_t *idx,
+                                       float *E_out, void *workspace, size_t ws_bytes, slk_stream_t stream) {
     SLK_REQUIRE(W && U && Q, "null pointer");
     SLK_REQUIRE(!unscale || scale, "unscale needs the row scales");
-    SLK_REQUIRE(R > 0 && n > 0, "empty layer");
+    SLK_REQUIRE(rows_per_layer > 0 && n > 0, "empty layer");
+    SLK_REQUIRE(batch >= 1 && batch <= 64, "batch must be 1..64");
+    SLK_REQUIRE(batch == 1 || rows_per_layer % TILE == 0, "a batch needs rows_per_layer to be a multiple of 64");
+    SLK_REQUIRE(batch == 1 || order, "a batch needs the column orders");
+    SLK_REQUIRE((long long)batch * rows_per_layer <= 0x7fffffffLL, "too many rows");
+    const int R = batch * rows_per_layer, rpl = rows_per_layer;
     SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
     SLK_REQUIRE(table == nullptr || levels <= 256, "general codebooks hold at most 256 entries");
     SLK_REQUIRE(idx == nullptr || levels <= 256, "uint8 indices need levels <= 256");
@@ -831,7 +856,7 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
     Arena ws(workspace, ws_bytes);
     float *Qp = ws.take<float>((size_t)R * n);
     float *Eg = ws.take<float>((size_t)R * n);
-    int *inv_order = ws.take<int>((size_t)n);
+    int *inv_order = ws.take<int>((size_t)batch * n);
     if (!Qp || !Eg || !inv_order) {
         set_error("workspace too small for a %d x %d layer", R, n);
         return SLK_E_WS;
@@ -866,9 +891,9 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
         perm_attr = true;
     }
     if (perm_lds)
-        SLK_RUN("permute_in", 0, 8.0 * R * n, s, k_permute_in_lds<<<R < 2048 ? R : 2048, 256, (size_t)n * 4, s>>>(W, scale, order, R, n, Qp, inv_order));
+        SLK_RUN("permute_in", 0, 8.0 * R * n, s, k_permute_in_lds<<<R < 2048 ? R : 2048, 256, (size_t)n * 4, s>>>(W, scale, order, R, n, Qp, inv_order, rpl));
     else
-        SLK_RUN("permute_in", 0, 8.0 * R * n, s, k_permute_in<<<R < 2048 ? R : 2048, 256, 0, s>>>(W, scale, order, R, n, Qp, inv_order));
+        SLK_RUN("permute_in", 0, 8.0 * R * n, s, k_permute_in<<<R < 2048 ? R : 2048, 256, 0, s>>>(W, scale, order, R, n, Qp, inv_order, rpl));
 
     Plan p;
     plan(0, n, min_block, num_blocks, p);
@@ -916,15 +941,15 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
                 if (in_lds && periods_ok && st.ops.size() <= (size_t)MAX_OPS && as_periods(st.ops, st.a, st.b, pt))
                     SLK_RUN("gptq_window", fl * R, wbytes, s,
                             k_gptq_window2<<<row_tiles, 512, sizeof(Window2Smem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g, inv_step,
-                                                                                      fast_ok, dbg & 24, pt));
+                                                                                      fast_ok, dbg & 24, pt, rpl));
                 else if (in_lds)
                     SLK_RUN("gptq_window", fl * R, wbytes, s,
                             k_gptq_window<true><<<row_tiles, 512, sizeof(WindowSmem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g,
-                                                                                        inv_step, fast_ok, dbg, tab));
+                                                                                        inv_step, fast_ok, dbg, tab, rpl));
                 else
                     SLK_RUN("gptq_window_wide", fl * R, wbytes, s,
                             k_gptq_window<false><<<row_tiles, 512, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, g, inv_step, fast_ok,
-                                                                           dbg, tab));
+                                                                           dbg, tab, rpl));
             }
         } else {
             const double K = st.b - st.a, N = st.c - st.b;
@@ -932,14 +957,14 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
             {
                 dim3 grid((st.c - st.b + TILE - 1) / TILE, (R + TILE - 1) / TILE);
                 SLK_RUN("gptq_trailing", 2.0 * R * K * N, 4.0 * R * K + 8.0 * K * N + 8.0 * R * N, s,
-                        k_gptq_trailing<<<grid, 256, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, st.b, st.c, vec_ok));
+                        k_gptq_trailing<<<grid, 256, 0, s>>>(Qp, Eg, U, R, n, st.a, st.b, st.b, st.c, vec_ok, rpl));
             }
         }
     }
     if (perm_lds)
-        SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out_lds<<<R < 2048 ? R : 2048, 256, (size_t)n * 4, s>>>(Qp, inv_order, R, n, g, unscale ? scale : nullptr, Q, idx));
+        SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out_lds<<<R < 2048 ? R : 2048, 256, (size_t)n * 4, s>>>(Qp, inv_order, R, n, g, unscale ? scale : nullptr, Q, idx, rpl));
     else
-        SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, unscale ? scale : nullptr, Q, idx));
+        SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, unscale ? scale : nullptr, Q, idx, rpl));
     if (E_out) SLK_HIP(hipMemcpyAsync(E_out, Eg, sizeof(float) * (size_t)R * n, hipMemcpyDeviceToDevice, s));
     return SLK_OK;
 }

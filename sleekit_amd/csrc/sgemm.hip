@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
                                                      const float *__restrict__ H, int R, int n,
                                                      float *__restrict__ G, float *__restrict__ partial,
                                                      int n_tiles, int vec_ok, const int *__restrict__ sym_flag,
-                                                     int bf16_takes_sym) {
+                                                     int bf16_takes_sym, int p_stride) {
     __shared__ Tile128Smem sm;
     __shared__ float rowpart[2][T32];
     // Column tiles are rotated by the row-tile index: with the symmetric shortcut below a tile's
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
     }
     __syncthreads();
     if (threadIdx.x < T32 && r0 + threadIdx.x < R)
-        partial[(size_t)(r0 + threadIdx.x) * n_tiles + tile_x] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
+        partial[(size_t)(r0 + threadIdx.x) * p_stride + tile_x] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
 }
 
 // x (or x - y when y is given), rows x n row-major -> its three bfloat16 pieces in the GEMM's own order:
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
 __global__ __launch_bounds__(256) void k_split3(const float *__restrict__ x, const float *__restrict__ y, int rows, int n,
                                                 unsigned short *__restrict__ out, size_t plane,
                                                 const int *__restrict__ sym_flag) {
-    if (sym_flag[0] == 0) return;
+    if (sym_flag && sym_flag[0] == 0) return;
     const int ksteps = n / 32;
     const size_t quads = plane / 4;  // groups of four consecutive k
     for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (size_t)gridDim.x * blockDim.x) {
@@ -190,8 +190,7 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
                                                           const unsigned short *__restrict__ Dp,
                                                           const unsigned short *__restrict__ Hp, int R, int n,
                                                           float *__restrict__ partial, int n_tiles,
-                                                          const int *__restrict__ sym_flag) {
-    if (sym_flag[0] == 0) return;
+                                                          const int *__restrict__ sym_flag, int p_stride, int cb, int rpl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TileBf16Smem &sm = *reinterpret_cast<TileBf16Smem *>(smem_raw);
     __shared__ float rowpart[2][T32];
@@ -202,17 +201,45 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
     // band's own D slabs stay in L2.  (Row-major slots left only two of the four rows resident at a time and
     // cost 1.9 GB past the L2 per launch.)  The column ranks go up and down the depths in groups of 8 so that
     // the tiles a CU gets over time (slots s, s + 32, ...) add up to the same depth.
+    //
+    // Few rows (a row shard of a multi-GPU run): the tiles alone do not fill the chip and the deepest one is the
+    // whole critical path, so K is cut into chunks of `cb` 128-blocks (cb > 0) and a tile of depth d = tile_x + 1
+    // blocks becomes ceil(d / cb) workgroups, each with its own slot of partial sums.  Workgroup order: the row
+    // tiles of one (column tile, chunk) are neighbours, so the H slabs they share are fetched once.
     const int n_rt = (R + T32 - 1) / T32;
-    const int rpx = (n_rt + 7) / 8, per_xcd = rpx * n_tiles;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    if (slot >= per_xcd) return;
-    const int rank = slot / rpx, tile_y = xcd * rpx + (slot - rank * rpx);
-    if (tile_y >= n_rt) return;
-    const int grp = rank >> 3, in_grp = rank & 7;
-    const int g_lo = grp * 8, g_hi = min(n_tiles, g_lo + 8) - 1;
-    const int tile_x = (grp & 1) ? g_hi - in_grp : g_lo + in_grp;
-    if (tile_x < g_lo || tile_x > g_hi) return;  // a last group shorter than 8
+    int tile_x, tile_y, p_slot, blk_lo, blk_hi;  // blocks [blk_lo, blk_hi) of K; block tile_x is the diagonal band
+    if (cb > 0) {
+        tile_y = blockIdx.x % n_rt;
+        int sl = blockIdx.x / n_rt;
+        p_slot = sl;
+        tile_x = 0;
+        while (tile_x < n_tiles && sl >= (tile_x + cb) / cb) {
+            sl -= (tile_x + cb) / cb;
+            ++tile_x;
+        }
+        if (tile_x >= n_tiles) return;
+        blk_lo = sl * cb;
+        blk_hi = min(blk_lo + cb, tile_x + 1);
+    } else {
+        const int rpx = (n_rt + 7) / 8, per_xcd = rpx * n_tiles;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        if (slot >= per_xcd) return;
+        const int rank = slot / rpx;
+        tile_y = xcd * rpx + (slot - rank * rpx);
+        if (tile_y >= n_rt) return;
+        const int grp = rank >> 3, in_grp = rank & 7;
+        const int g_lo = grp * 8, g_hi = min(n_tiles, g_lo + 8) - 1;
+        tile_x = (grp & 1) ? g_hi - in_grp : g_lo + in_grp;
+        if (tile_x < g_lo || tile_x > g_hi) return;  // a last group shorter than 8
+        p_slot = tile_x;
+        blk_lo = 0;
+        blk_hi = tile_x + 1;
+    }
     const int r0 = tile_y * T32, j0 = tile_x * T32;
+    // a batch of layers stacked by rows (rpl rows each, a multiple of the tile): layer b has its own flag and planes of H
+    const int layer = r0 / rpl;
+    if (sym_flag[layer] == 0) return;
+    Hp += (size_t)layer * 3 * n * n;
     const int t = threadIdx.x;
     Acc128 acc;
     acc.zero();
@@ -236,8 +263,9 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
             for (int h = 0; h < 2; ++h) v[p][h] = *reinterpret_cast<const uint4v_t *>(q + p * h_plane + 8 * h);
     };
     // sum_k D_k H_kj over all k == 2 * sum_{k < j0} + the 128-wide diagonal band (see k_error_tiles)
-    if (j0 > 0) {
-        tile128_mac_planes(acc, sm, 0, j0, la, lb);
+    const int k_lo = blk_lo * T32, k_below = min(blk_hi * T32, j0);  // [k_lo, k_below) lies under the band: twice
+    if (k_below > k_lo) {
+        tile128_mac_planes(acc, sm, k_lo, k_below, la, lb);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -246,7 +274,7 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
                 for (int r = 0; r < 16; ++r) acc.c[i][j][r] = acc.c[i][j][r] * 2.0f;
         __syncthreads();
     }
-    tile128_mac_planes(acc, sm, j0, j0 + T32, la, lb);
+    if (blk_hi == tile_x + 1) tile128_mac_planes(acc, sm, j0, j0 + T32, la, lb);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -271,29 +299,63 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
     }
     __syncthreads();
     if (threadIdx.x < T32 && r0 + threadIdx.x < R)
-        partial[(size_t)(r0 + threadIdx.x) * n_tiles + tile_x] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
+        partial[(size_t)(r0 + threadIdx.x) * p_stride + p_slot] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
 }
 
-// flag[0] = 1 iff H is bit-wise symmetric (flag must be preset to 1).
+// flag[0] = 1 iff H is bit-wise symmetric (flag must be preset to 1).  One workgroup per pair of mirrored
+// 64 x 64 tiles (a triangular list of pairs): tile (bi, bj) goes to LDS through coalesced 16-byte loads, tile
+// (bj, bi) is read the same way and compared with the transpose out of LDS -- every element is read once.
 __global__ __launch_bounds__(256) void k_symmetry_flag(const float *__restrict__ H, int n, int *__restrict__ flag) {
-    __shared__ float tile[32][33];
-    const int bi = blockIdx.y, bj = blockIdx.x;
-    if (bj > bi) return;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    __shared__ float tile[64][65];
+    // pair index -> (bi >= bj)
+    int bi = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+    while ((bi + 1) * (bi + 2) / 2 <= (int)blockIdx.x) ++bi;
+    while (bi * (bi + 1) / 2 > (int)blockIdx.x) --bi;
+    const int bj = (int)blockIdx.x - bi * (bi + 1) / 2;
+    const int t = threadIdx.x, c4 = (t & 15) * 4, r_first = t >> 4;  // 16 threads x 16 bytes per row, 16 rows per pass
+    const bool vec = n % 4 == 0 && (uintptr_t)H % 16 == 0;
     bool ok = true;
-    for (int r = ty; r < 32; r += 8) {
-        const int i = bj * 32 + r, j = bi * 32 + tx;  // the mirrored tile, read row-wise
-        tile[r][tx] = (i < n && j < n) ? H[(size_t)i * n + j] : 0.0f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r_first + 16 * p, i = bi * 64 + r, j = bj * 64 + c4;
+        float4_t v = (float4_t){0.0f, 0.0f, 0.0f, 0.0f};
+        if (i < n) {
+            if (vec && j + 3 < n) {
+                v = *reinterpret_cast<const float4_t *>(H + (size_t)i * n + j);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (j + e < n) v[e] = H[(size_t)i * n + j + e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r][c4 + e] = v[e];
     }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int i = bi * 32 + r, j = bj * 32 + tx;
-        if (i < n && j < n) ok = ok && (__float_as_int(H[(size_t)i * n + j]) == __float_as_int(tile[tx][r]));
+    {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = r_first + 16 * p, i = bj * 64 + r, j = bi * 64 + c4;  // the mirrored tile, read row-wise
+            if (i >= n) continue;
+            float4_t v = (float4_t){0.0f, 0.0f, 0.0f, 0.0f};
+            if (vec && j + 3 < n) {
+                v = *reinterpret_cast<const float4_t *>(H + (size_t)i * n + j);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (j + e < n) v[e] = H[(size_t)i * n + j + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (j + e < n) ok = ok && (__float_as_int(v[e]) == __float_as_int(tile[c4 + e][r]));
+        }
     }
     if (!ok) flag[0] = 0;
 }
 
-__global__ void k_set_flag(int *flag, int v) { flag[0] = v; }
+__global__ void k_set_flag(int *flag, int v, int count) {
+    if ((int)threadIdx.x < count) flag[threadIdx.x] = v;
+}
 
 __global__ __launch_bounds__(256) void k_error_reduce(const float *__restrict__ partial, int R, int n_tiles,
                                                       float *__restrict__ row_err) {
@@ -431,31 +493,59 @@ using namespace slk;
 
 extern "C" {
 
-int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n, float *row_err, float *G,
-                   void *workspace, size_t ws_bytes, slk_stream_t stream) {
-    SLK_REQUIRE(W && Q && H && row_err && R > 0 && n > 0, "bad arguments");
+static int row_errors_impl(const float *W, const float *Q, const float *const *Hs, int batch, int rpl, int n, float *row_err,
+                           float *G, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+    const int R = batch * rpl;
     const int n_tiles = (n + T32 - 1) / T32;
     Arena ws(workspace, ws_bytes);
-    float *partial = ws.take<float>((size_t)R * n_tiles);
+    // K split of the bfloat16 kernel for few rows (see the kernel): the largest chunk that still gives >= 512 workgroups
+    const int n_rt = (R + T32 - 1) / T32;
+    int cb = 0, n_slots = n_tiles;
+    if (G == nullptr && n_rt * n_tiles < 512 && getenv("SLK_NO_ERROR_SPLITK") == nullptr) {
+        const char *force = getenv("SLK_ERROR_CB");
+        for (int c = force ? atoi(force) : 16; c >= 2; c >>= 1) {
+            int slots = 0;
+            for (int x = 0; x < n_tiles; ++x) slots += (x + c) / c;
+            if (slots > 4 * n_tiles) break;
+            cb = c;
+            n_slots = slots;
+            if (n_rt * slots >= 512 || force) break;
+        }
+    }
+    float *partial = ws.take<float>((size_t)R * n_slots);
     int *sym = ws.take<int>(64);
     if (!partial || !sym) {
         set_error("workspace too small");
         return SLK_E_WS;
     }
     hipStream_t s = as_stream(stream);
-    const int n_all = n_tiles * ((R + T32 - 1) / T32);
-    dim3 grid(8 * ((n_all + 7) / 8));  // a multiple of the 8 XCDs: see the tile order in the kernel
-    const int vec_ok = n % 4 == 0 && ((uintptr_t)W | (uintptr_t)Q | (uintptr_t)H) % 16 == 0;
+    if (cb > 0) SLK_HIP(hipMemsetAsync(partial, 0, (size_t)R * n_slots * sizeof(float), s));  // the float32 kernel fills n_tiles slots only
+    const int rt_layer = (rpl + T32 - 1) / T32;  // row tiles of one layer
+    dim3 grid(8 * ((n_tiles * rt_layer + 7) / 8));  // a multiple of the 8 XCDs: see the tile order in the kernel
+    bool aligned = ((uintptr_t)W | (uintptr_t)Q) % 16 == 0;
+    for (int b = 0; b < batch; ++b) aligned = aligned && (uintptr_t)Hs[b] % 16 == 0;
+    const int vec_ok = n % 4 == 0 && aligned;
     const bool try_sym = G == nullptr && getenv("SLK_NO_SYM_ERROR") == nullptr;
     if (try_sym) {
-        SLK_RUN("set_flag", 0, 4, s, k_set_flag<<<1, 1, 0, s>>>(sym, 1));
-        const int t32 = (n + 31) / 32;
-        SLK_RUN("symmetry_check", 0, 4.0 * n * n, s, k_symmetry_flag<<<dim3(t32, t32), 256, 0, s>>>(H, n, sym));
+        SLK_RUN("set_flag", 0, 4, s, k_set_flag<<<1, 64, 0, s>>>(sym, 1, batch));
+        const int t64 = (n + 63) / 64;
+        for (int b = 0; b < batch; ++b)
+            SLK_RUN("symmetry_check", 0, 4.0 * n * n, s, k_symmetry_flag<<<t64 * (t64 + 1) / 2, 256, 0, s>>>(Hs[b], n, sym + b));
     }
     // the symmetric case goes to the bfloat16 x 3 kernel when the shape allows (16-byte loads, whole tiles of columns)
-    const size_t d_plane = (size_t)((R + T32 - 1) / T32) * T32 * n;  // rows padded to whole tiles
-    unsigned short *Dp = ws.take<unsigned short>(3 * d_plane), *Hp = ws.take<unsigned short>(3 * (size_t)n * n);
+    const size_t d_plane = (size_t)n_rt * T32 * n;  // rows padded to whole tiles
+    unsigned short *Dp = ws.take<unsigned short>(3 * d_plane), *Hp = ws.take<unsigned short>(3 * (size_t)n * n * batch);
     const int bf16_ok = try_sym && vec_ok && n % T32 == 0 && Dp && Hp && getenv("SLK_NO_BF16_ERROR") == nullptr;
+    if (batch > 1 && !(Dp && Hp)) {
+        set_error("workspace too small for the operand planes of %d layers (slk_workspace_bytes_batch)", batch);
+        return SLK_E_WS;
+    }
+    // one layer's rows through the float32 kernel (every k when its H is not symmetric)
+    auto f32_layer = [&](int b, const int *flag, int bf16_takes_sym) {
+        const size_t o = (size_t)b * rpl;
+        k_error_tiles<<<grid, 256, 0, s>>>(W + o * n, Q + o * n, Hs[b], rpl, n, G, partial + o * n_slots, n_tiles, vec_ok, flag,
+                                           bf16_takes_sym, n_slots);
+    };
     // algorithmic flops: the definition (2 R n^2) whichever way they are obtained
     if (bf16_ok) {
         static bool attr_set = false;
@@ -464,22 +554,40 @@ int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TileBf16Smem)));
             attr_set = true;
         }
-        SLK_RUN("error_split", 0, 14.0 * R * n + 10.0 * n * n, s, k_split3<<<2048, 256, 0, s>>>(W, Q, R, n, Dp, d_plane, sym));
-        SLK_RUN("error_split", 0, 0, s, k_split3<<<2048, 256, 0, s>>>(H, nullptr, n, n, Hp, (size_t)n * n, sym));
+        SLK_RUN("error_split", 0, 14.0 * R * n, s,
+                k_split3<<<2048, 256, 0, s>>>(W, Q, R, n, Dp, d_plane, batch == 1 ? sym : nullptr));
+        for (int b = 0; b < batch; ++b)
+            SLK_RUN("error_split", 0, 10.0 * n * n, s,
+                    k_split3<<<2048, 256, 0, s>>>(Hs[b], nullptr, n, n, Hp + (size_t)b * 3 * n * n, (size_t)n * n, sym + b));
         // flops as executed: six bfloat16 products per float32 product, over k <= j only (the definition of the
         // layer error, SURVEY.md 8d, counts 2 R n^2 float32 flops: a third of this, twice over)
-        const int n_rt = (R + T32 - 1) / T32;
-        const dim3 grid16(8 * ((n_rt + 7) / 8) * ((n_tiles + 7) / 8 * 8));  // see the tile order in the kernel
-        SLK_RUN("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n, s,
-                k_error_tiles_bf16<<<grid16, 256, sizeof(TileBf16Smem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym));
-        SLK_RUN("error_gemm_f32", 0, 0, s,
-                k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles, vec_ok, sym, 1));
+        const int wgs = cb > 0 ? n_rt * n_slots : 8 * ((n_rt + 7) / 8) * ((n_tiles + 7) / 8 * 8);  // see the tile order in the kernel
+        SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, cb > 0 ? wgs : n_rt * n_tiles, s,
+                  k_error_tiles_bf16<<<wgs, 256, sizeof(TileBf16Smem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym, n_slots, cb,
+                                                                            batch == 1 ? R : rpl));
+        for (int b = 0; b < batch; ++b) SLK_RUN("error_gemm_f32", 0, 0, s, f32_layer(b, sym + b, 1));
     } else {
-        SLK_RUN("error_gemm", 2.0 * R * n * n, 8.0 * R * n + 4.0 * n * n + (G ? 4.0 * R * n : 0.0), s,
-                k_error_tiles<<<grid, 256, 0, s>>>(W, Q, H, R, n, G, partial, n_tiles, vec_ok, try_sym ? sym : nullptr, 0));
+        for (int b = 0; b < batch; ++b)
+            SLK_RUN("error_gemm", 2.0 * rpl * n * n, 8.0 * rpl * n + 4.0 * n * n + (G ? 4.0 * rpl * n : 0.0), s,
+                    f32_layer(b, try_sym ? sym + b : nullptr, 0));
     }
-    SLK_RUN("error_reduce", 0, 4.0 * R * n_tiles, s, k_error_reduce<<<(R + 255) / 256, 256, 0, s>>>(partial, R, n_tiles, row_err));
+    SLK_RUN("error_reduce", 0, 4.0 * R * n_slots, s, k_error_reduce<<<(R + 255) / 256, 256, 0, s>>>(partial, R, n_slots, row_err));
     return SLK_OK;
+}
+
+int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n, float *row_err, float *G,
+                   void *workspace, size_t ws_bytes, slk_stream_t stream) {
+    SLK_REQUIRE(W && Q && H && row_err && R > 0 && n > 0, "bad arguments");
+    return row_errors_impl(W, Q, &H, 1, R, n, row_err, G, workspace, ws_bytes, stream);
+}
+
+int slk_row_errors_batch(const float *W, const float *Q, const float *const *H, int batch, int rows_per_layer, int n,
+                         float *row_err, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+    SLK_REQUIRE(W && Q && H && row_err && rows_per_layer > 0 && n > 0, "bad arguments");
+    SLK_REQUIRE(batch >= 1 && batch <= 64, "batch must be 1..64");
+    SLK_REQUIRE(batch == 1 || rows_per_layer % T32 == 0, "a batch needs rows_per_layer to be a multiple of 128");
+    for (int b = 0; b < batch; ++b) SLK_REQUIRE(H[b], "null Hessian in the batch");
+    return row_errors_impl(W, Q, H, batch, rows_per_layer, n, row_err, nullptr, workspace, ws_bytes, stream);
 }
 
 int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, long long count_before,

@@ -86,7 +86,7 @@ __device__ __forceinline__ void leaf_chain(const LeafTables &lt, int c16, float 
 
 __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, float *__restrict__ Eg,
                                                       const double *__restrict__ U, int R, int n, int w0, int w1,
-                                                      Grid g, float inv_step, int fast_ok, int prof, PeriodTable tab) {
+                                                      Grid g, float inv_step, int fast_ok, int prof, PeriodTable tab, int rpl) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Window2Smem &sm = *reinterpret_cast<Window2Smem *>(smem_raw);
     // readfirstlane: tells the compiler the wave index is wave-uniform (scalar branches, SGPR addressing)
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
     const int role_wave = (wave & 1) + ((wave >> 2) << 1);  // 0-3 within the role
     const int ht = role_wave * 64 + lane;                   // thread index within the role, 0-255
     const int r0 = blockIdx.x * RB;
+    U += (size_t)(r0 / rpl) * n * n;  // a batch of layers stacked by rows: rows [b rpl, (b + 1) rpl) use factor b
     const int np = tab.count;
     const int width = w1 - w0;
     if (g.table) {  // the leaves search the codebook once per column: keep it next to them

@@ -57,7 +57,10 @@ class HipBackend:
             return None, None, None
         if not hasattr(self, "_streams"):
             nf, nl = (self.overlap if isinstance(self.overlap, tuple) else (2, 2))
-            self._streams = ([torch.cuda.Stream() for _ in range(nf)], torch.cuda.Stream(),
+            import os
+
+            prio = int(os.environ.get("SLK_FACTOR_PRIORITY", "0"))  # EXPERIMENT
+            self._streams = ([torch.cuda.Stream(priority=prio) for _ in range(nf)], torch.cuda.Stream(priority=prio),
                              [torch.cuda.Stream() for _ in range(nl)])
         return self._streams
 
@@ -111,6 +114,40 @@ class HipBackend:
         res = eng.quantize_layer(W, layer["H"], self.quantizer, sc, self.act_order, self.damp, self.moves, factor=factor)
         err = eng.row_errors(W, res.Q, layer["H"]) if self.with_error else None
         return dict(Q=res.Q, idx=res.idx, row_err=err, rows=(lo, hi))
+
+
+    # -- a whole round at once: the row shards of the G layers of a round go through every kernel together
+    def can_batch(self, round_layers, lo, hi):
+        if self.moves or len(round_layers) < 2 or len(round_layers) > 64 or (hi - lo) % 128 != 0 or hi == lo:
+            return False
+        first = round_layers[0]
+        scaled = first.get("scale") is not None
+        return all(lay["W"].shape == first["W"].shape and lay["H"].shape == first["H"].shape
+                   and (lay.get("scale") is not None) == scaled for lay in round_layers)
+
+    def run_round(self, round_layers, lo, hi, payloads):
+        """Shards of the round's layers from their packed factors: unpack into one stacked factor, ONE loop and
+        ONE error evaluation over all the layers (engine.run_loop_batch) -- R / G rows of a single layer leave
+        most of the chip idle, the round's G shards together are a full layer's worth of rows."""
+        from . import _device as dev
+        from . import _lib
+
+        eng = self.engine
+        B, n = len(round_layers), round_layers[0]["H"].shape[0]
+        device = round_layers[0]["W"].device
+        U = torch.empty((B, n, n), dtype=torch.float64, device=device)
+        order = torch.empty((B, n), dtype=torch.int64, device=device)
+        info = torch.empty(B, dtype=torch.int32, device=device)
+        for b, payload in enumerate(payloads):
+            _lib.check(_lib.lib.slk_factor_unpack(dev.ptr(payload), n, U[b].data_ptr(), order[b].data_ptr(),
+                                                  info[b:b + 1].data_ptr(), dev.stream_handle()))
+        W = torch.stack([lay["W"][lo:hi] for lay in round_layers])
+        sc = torch.stack([lay["scale"][lo:hi] for lay in round_layers]) if round_layers[0].get("scale") is not None else None
+        cb = eng.require_uniform(self.quantizer)
+        Q, idx = eng.run_loop_batch(W, sc, order, U, cb, 32, 8, unscale=sc is not None)
+        err = eng.row_errors_batch(W, Q, [lay["H"] for lay in round_layers]) if self.with_error else None
+        return [dict(Q=Q[b], idx=idx[b], row_err=None if err is None else err[b], rows=(lo, hi), info=info[b:b + 1])
+                for b in range(B)]
 
 
 class _NullCtx:
@@ -170,9 +207,14 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
 
     # 1. every rank factors the layers it is the root of (concurrently across ranks); the
     #    factorisations are latency-bound chains, so consecutive ones alternate between streams
+    #    (the rotation carries on from the previous call: with one layer per rank and call -- a round of G
+    #    layers on G ranks -- consecutive calls would otherwise queue on the same stream, one chain behind the other)
     mine = list(range(rank, n_layers, size))
+    first = getattr(backend, "_factor_rotation", 0) if side else 0
+    if side:
+        backend._factor_rotation = (first + len(mine)) % len(fstreams)
     for k, l in enumerate(mine):
-        fs = fstreams[k % len(fstreams)] if side else None
+        fs = fstreams[(first + k) % len(fstreams)] if side else None
         if side and k < len(fstreams):
             fs.wait_stream(here)
         with on(fs):
@@ -204,31 +246,54 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
                     payload = backend.alloc_payload(words, dev_).zero_()
                 gathered[g] = _all_gather_words(payload, size)
                 keep.append(payload)
-    # 3. every rank runs its rows of every layer as the factors land (loops of consecutive layers
-    #    alternate between streams too: their leaf chains are latency-bound as well)
+    # 3. every rank runs its rows of every layer as the factors land, round by round.  A round whose layers
+    #    share one shape goes through the kernels as ONE batch when the backend can do that (run_round): the
+    #    shards are R / G rows each, too few to fill the chip alone.  Otherwise layer by layer, consecutive
+    #    ones on alternating streams (their leaf chains are latency-bound).
     out = []
-    for l, layer in enumerate(layers):
-        ls = lstreams[l % len(lstreams)] if side else None
-        if side and l < len(lstreams):
-            ls.wait_stream(here)
-        with on(ls):
-            if exchange:
-                parts, work = gathered[l // size]
+    if side:
+        for st in lstreams:
+            st.wait_stream(here)
+    # (batched rounds rotate over the loop streams across calls, like the factorisations above)
+    batched_rounds = getattr(backend, "_loop_rotation", 0) if side else 0
+    for g in range(n_rounds):
+        members = list(range(g * size, min((g + 1) * size, n_layers)))
+        lo, hi = row_range(layers[members[0]]["W"].shape[0], rank, size)
+        if exchange and hasattr(backend, "run_round") and backend.can_batch([layers[l] for l in members], lo, hi):
+            ls = lstreams[batched_rounds % len(lstreams)] if side else None
+            batched_rounds += 1
+            if side:
+                backend._loop_rotation = batched_rounds % len(lstreams)
+            with on(ls):
+                parts, work = gathered[g]
                 work.wait()  # orders the stream behind the transfer; no host block on GPU
-                if factors[l] is None or always_exchange:
-                    factors[l] = backend.unpack(parts[l % size], layer["H"].shape[0])
-            elif ready[l] is not None:
-                ls.wait_event(ready[l])
-            lo, hi = row_range(layer["W"].shape[0], rank, size)
-            shard = backend.run_rows(layer, lo, hi, factors[l])
-            if side:  # made on a factor / comm stream, read on this one
-                for t in factors[l]:
-                    t.record_stream(ls)
-                if exchange:
-                    for t in gathered[l // size][0]:
+                shards = backend.run_round([layers[l] for l in members], lo, hi, [parts[l % size] for l in members])
+                if side:
+                    for t in parts:
                         t.record_stream(ls)
-        shard["info"] = factors[l][2]
-        out.append(shard)
+            out.extend(shards)
+            continue
+        for l in members:
+            layer = layers[l]
+            ls = lstreams[l % len(lstreams)] if side else None
+            with on(ls):
+                if exchange:
+                    parts, work = gathered[g]
+                    work.wait()
+                    if factors[l] is None or always_exchange:
+                        factors[l] = backend.unpack(parts[l % size], layer["H"].shape[0])
+                elif ready[l] is not None:
+                    ls.wait_event(ready[l])
+                lo, hi = row_range(layer["W"].shape[0], rank, size)
+                shard = backend.run_rows(layer, lo, hi, factors[l])
+                if side:  # made on a factor / comm stream, read on this one
+                    for t in factors[l]:
+                        t.record_stream(ls)
+                    if exchange:
+                        for t in gathered[g][0]:
+                            t.record_stream(ls)
+            shard["info"] = factors[l][2]
+            out.append(shard)
     if side:
         if join:
             for st in lstreams:
@@ -236,7 +301,7 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
         # tensors made on the side streams are consumed on the caller's stream: keep the allocator honest
         extra = [(p,) for p in keep] + [tuple(g[0]) for g in gathered if g is not None]
         for f in factors + extra:
-            for t in f:
+            for t in f or ():
                 t.record_stream(here)
         for shard in out:
             for t in shard.values():

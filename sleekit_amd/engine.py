@@ -129,6 +129,43 @@ def run_loop(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=True, w
     return Q, idx, E
 
 
+def run_loop_batch(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=True, unscale=False):
+    """The loop over a batch of layers stacked by rows (slk_gptq_quantize_batch).
+
+    W (B, R, n) float32, scale (B, R) or None, order (B, n) int64, U (B, n, n) float64, all contiguous.
+    Returns (Q, idx) shaped (B, R, n): what B calls of run_loop return, in launches that cover all B layers.
+    """
+    B, R, n = W.shape
+    assert order.shape == (B, n) and U.shape == (B, n, n) and (scale is None or scale.shape == (B, R))
+    assert W.is_contiguous() and order.is_contiguous() and U.is_contiguous() and (scale is None or scale.is_contiguous())
+    levels, lo, hi, table = cb_abi
+    ws, ws_bytes = dev.workspace(R, n, batch=B)
+    Q = torch.empty((B, R, n), dtype=torch.float32, device=W.device)
+    idx = torch.empty((B, R, n), dtype=torch.uint8, device=W.device) if want_idx else None
+    _lib.check(
+        _lib.lib.slk_gptq_quantize_batch(
+            dev.ptr(W), dev.ptr(scale), dev.ptr(order), dev.ptr(U), B, R, n, levels, lo, hi, dev.ptr(table), int(min_block),
+            int(num_blocks), 1 if unscale else 0, dev.ptr(Q), dev.ptr(idx), None, dev.ptr(ws), ws_bytes, dev.stream_handle(),
+        )
+    )
+    return Q, idx
+
+
+def row_errors_batch(W, Q, Hs):
+    """Row errors of a batch of layers stacked by rows: W, Q (B, R, n); Hs a list of B (n, n) float32 tensors."""
+    import ctypes
+
+    B, R, n = W.shape
+    assert len(Hs) == B and W.is_contiguous() and Q.is_contiguous()
+    ws, ws_bytes = dev.workspace(R, n, batch=B)
+    out = torch.empty((B, R), dtype=torch.float32, device=W.device)
+    ptrs = (ctypes.c_void_p * B)(*[dev.ptr(H) for H in Hs])
+    _lib.check(
+        _lib.lib.slk_row_errors_batch(dev.ptr(W), dev.ptr(Q), ptrs, B, R, n, dev.ptr(out), dev.ptr(ws), ws_bytes, dev.stream_handle())
+    )
+    return out
+
+
 def local_search(W, Q, H, cb_abi, moves, idx=None):
     """In place on Q (and idx)."""
     R, n = W.shape

@@ -1,0 +1,58 @@
+"""Helper of test_gpu_parity.py::test_batched_rounds_two_ranks_one_gpu (launched by torch.distributed.run, 2 ranks).
+
+Both ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one GPU): the row shards of a round's
+layers go through the batched loop (HipBackend.run_round) and must equal, bit for bit, the rows of the
+unsharded single-GPU result; a ragged layer and a lone last layer take the layer-by-layer route in the same call.
+"""
+
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+from sleekit_amd import codebook, engine, synth  # noqa: E402
+from sleekit_amd import dist as sdist  # noqa: E402
+
+
+def main():
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    dist.init_process_group("gloo")
+    rank, size = dist.get_rank(), dist.get_world_size()
+    cb = codebook.UniformCodebook(8, -1, 1)
+    shapes = [(256, 512), (256, 512), (512, 1024), (512, 1024), (100, 192), (64, 192), (256, 320)]
+    layers = []
+    for i, (R, n) in enumerate(shapes):
+        lay = synth.make_layer(R, n, 300 + i)
+        layers.append({k: torch.from_numpy(lay[k]).to(device) for k in ("W", "H", "scale")})
+    layers[1]["H"] = layers[1]["H"].clone()
+    layers[1]["H"][2, 5] += 0.125  # not symmetric: that layer's error takes the float32 kernel inside the batch
+    calls = {"round": 0, "rows": 0}
+    for overlap in ((2, 2), False):
+        backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True, overlap=overlap)
+        run_round, run_rows = backend.run_round, backend.run_rows
+        backend.run_round = lambda *a: (calls.__setitem__("round", calls["round"] + 1), run_round(*a))[1]
+        backend.run_rows = lambda *a: (calls.__setitem__("rows", calls["rows"] + 1), run_rows(*a))[1]
+        shards = sdist.quantize_stream(layers, backend)
+        torch.cuda.synchronize()
+        for lay, sh in zip(layers, shards):
+            lo, hi = sh["rows"]
+            assert (lo, hi) == sdist.row_range(lay["W"].shape[0], rank, size)
+            res = engine.quantize_layer(lay["W"], lay["H"], cb, lay["scale"])
+            err = engine.row_errors(lay["W"], res.Q, lay["H"])
+            assert np.array_equal(sh["Q"].cpu().numpy(), res.Q[lo:hi].cpu().numpy())
+            assert np.array_equal(sh["idx"].cpu().numpy(), res.idx[lo:hi].cpu().numpy())
+            np.testing.assert_allclose(sh["row_err"].cpu().numpy(), err[lo:hi].cpu().numpy(), rtol=1e-5)
+            assert int(sh["info"].item()) == 0
+    assert calls["round"] == 2 * 2 and calls["rows"] == 2 * 3, calls  # rounds (0,1), (2,3) batched; (4,5) ragged, (6) alone
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"DIST_ROUND_OK rank {rank}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -401,6 +401,17 @@ def test_layer_error_bf16_path(amd, monkeypatch):
     monkeypatch.delenv("SLK_NO_BF16_ERROR")
     np.testing.assert_allclose(got32, want, rtol=1e-5)
     np.testing.assert_allclose(got, got32, rtol=2e-6)
+    # few rows: K is cut into chunks so that the tiles fill the chip (a row shard of a multi-GPU run); every chunk
+    # size, and the uncut kernel, within rounding of each other
+    for chunk in ("2", "4", "8", "16"):
+        monkeypatch.setenv("SLK_ERROR_CB", chunk)
+        np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, H), want, rtol=1e-5)
+    monkeypatch.delenv("SLK_ERROR_CB")
+    monkeypatch.setenv("SLK_NO_ERROR_SPLITK", "1")
+    whole = amd.obq.channelwise_error(W, Q, H)
+    monkeypatch.delenv("SLK_NO_ERROR_SPLITK")
+    np.testing.assert_allclose(whole, want, rtol=1e-5)
+    np.testing.assert_allclose(got, whole, rtol=2e-6)
     Ha = H.copy()
     Ha[3, 7] += np.float32(0.25)  # not symmetric: every k is multiplied
     want_a = ((D @ Ha.astype(np.float64)) * D).sum(axis=1)
@@ -680,3 +691,72 @@ def test_exchange_over_rccl_single_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, script, "29643"], capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode == 0 and "RCCL_SINGLE_RANK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_batched_rounds_two_ranks_one_gpu():
+    """Two ranks on this one GPU (gloo): the batched rounds of sleekit_amd.dist against the unsharded result."""
+    import subprocess
+    import sys
+
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_round_gpu.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29657", script]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0 and out.stdout.count("DIST_ROUND_OK") == 2, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.parametrize("B,R,n", [(3, 128, 320), (2, 256, 1024), (4, 128, 1100)])
+def test_batch_entry_points(amd, B, R, n):
+    """slk_gptq_quantize_batch / slk_row_errors_batch: B layers stacked by rows == B separate calls."""
+    eng = amd.engine
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    abi = eng.require_uniform(cb)
+    Ls = [layer(R, n, 5100 + 7 * b + n) for b in range(B)]
+    dev_ = torch.device("cuda")
+    W = torch.stack([torch.from_numpy(L["W"]) for L in Ls]).to(dev_)
+    sc = torch.stack([torch.from_numpy(L["scale"]) for L in Ls]).to(dev_)
+    Hs = [torch.from_numpy(L["H"]).to(dev_) for L in Ls]
+    Hs[-1] = Hs[-1].clone()
+    Hs[-1][1, 3] += 0.25  # the last layer's Hessian is not symmetric: float32 kernel, every k
+    facs = [eng.factorize(H, n, 0.01, amd.lib.ORDER_MODES["diag"]) for H in Hs]
+    order = torch.stack([f[0] for f in facs])
+    U = torch.stack([f[1] for f in facs])
+    for scale, unscale in ((sc, True), (sc, False), (None, False)):
+        Q, idx = eng.run_loop_batch(W, scale, order, U, abi, 32, 8, unscale=unscale)
+        for b in range(B):
+            q1, i1, _ = eng.run_loop(W[b], None if scale is None else scale[b], facs[b][0], facs[b][1], abi, 32, 8, unscale=unscale)
+            assert torch.equal(Q[b], q1) and torch.equal(idx[b], i1), (b, unscale)
+    Q, _ = eng.run_loop_batch(W, sc, order, U, abi, 32, 8, unscale=True)
+    err = eng.row_errors_batch(W, Q, Hs)
+    for b in range(B):
+        want = ((W[b] - Q[b]).double() @ Hs[b].double() * (W[b] - Q[b]).double()).sum(dim=1)
+        np.testing.assert_allclose(err[b].cpu().numpy(), want.cpu().numpy(), rtol=1e-5)
+        np.testing.assert_allclose(err[b].cpu().numpy(), eng.row_errors(W[b], Q[b], Hs[b]).cpu().numpy(), rtol=4e-6)
+    # argument checks of the batch forms
+    assert amd.lib.lib.slk_gptq_quantize_batch(W.data_ptr(), None, order.data_ptr(), U.data_ptr(), 2, 100, n, 8, -1.0, 1.0, None, 32, 8, 0,
+                                               Q.data_ptr(), None, None, None, 0, None) == amd.lib.E_ARG
+    assert b"multiple of 64" in amd.lib.lib.slk_last_error()
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 130, 516, 1100])
+def test_symmetry_verdict_at_the_edges(amd, n):
+    """The layer error halves its work when H is bit-wise symmetric: a single asymmetric entry anywhere --
+    corners, tile seams, the ragged last tile -- must send it down the general route (obq.py:89-95 takes any H)."""
+    rng = np.random.default_rng(n)
+    R = 9
+    W = rng.standard_normal((R, n)).astype(np.float32)
+    Q = (W + 0.3 * rng.standard_normal((R, n))).astype(np.float32)
+    X = rng.standard_normal((n + 3, n)).astype(np.float32)
+    H = (X.T @ X).astype(np.float32)
+    H = ((H + H.T) * np.float32(0.5)).astype(np.float32)
+    D = (W - Q).astype(np.float64)
+    np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, H), ((D @ H.astype(np.float64)) * D).sum(axis=1), rtol=1e-5)
+    spots = {(0, n - 1), (n - 1, 0), (n // 2, n - 1), (min(63, n - 1), min(64, n - 1)), (min(64, n - 1), 0), (n - 1, n // 3)}
+    for i, j in sorted(spots):
+        if i == j:
+            continue
+        Ha = H.copy()
+        Ha[i, j] += np.float32(n) * (np.float32(1.0) + abs(Ha[i, j]))  # large enough to show in every row's error
+        want = ((D @ Ha.astype(np.float64)) * D).sum(axis=1)
+        np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, Ha), want, rtol=1e-5, atol=1e-5 * np.abs(want).max(), err_msg=str((i, j)))

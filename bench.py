@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic layers cycled through the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts (default 3,2; 3,min(8,2N) on N>1 ranks)")
+    ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts (default 3,2)")
     ap.add_argument("--stages", action="store_true", help="also print per-kernel timing table to stderr")
     return ap.parse_args()
 
@@ -102,8 +102,8 @@ def main():
         host_layer0 = {k: base[0][k].cpu().numpy() for k in ("W", "H", "scale")}
     t_setup = time.time() - t_setup
 
-    # row shards shrink with N while the leaf chains do not: more loops in flight on more ranks
-    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else (3, 2 if world == 1 else min(8, 2 * world))
+    # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: two loop streams still)
+    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else (3, 2)
     backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=streams)
 
     def step():

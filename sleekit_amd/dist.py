@@ -57,10 +57,7 @@ class HipBackend:
             return None, None, None
         if not hasattr(self, "_streams"):
             nf, nl = (self.overlap if isinstance(self.overlap, tuple) else (2, 2))
-            import os
-
-            prio = int(os.environ.get("SLK_FACTOR_PRIORITY", "0"))  # EXPERIMENT
-            self._streams = ([torch.cuda.Stream(priority=prio) for _ in range(nf)], torch.cuda.Stream(priority=prio),
+            self._streams = ([torch.cuda.Stream() for _ in range(nf)], torch.cuda.Stream(),
                              [torch.cuda.Stream() for _ in range(nl)])
         return self._streams
 

@@ -277,18 +277,18 @@ __global__ __launch_bounds__(256) void k_trtri_level(const double *__restrict__ 
     const int t = threadIdx.x;
     if (STAGE == 0) {
         const double *pa = L + ((size_t)bi * TILE + (t >> 2)) * ld + (t & 3) * 8;
-        const double *pb = X + (size_t)(t >> 3) * ld + (size_t)bj * TILE + (t & 7) * 8;
+        const double *pb = X + (size_t)(t >> 3) * ld + (size_t)bj * TILE + (t & 7) * 2;
         tile64_mac<true>(
             acc, sm, bj * TILE, mid * TILE, [&](int k0, double(&v)[8]) { load8d<true>(pa + k0, v); },
-            [&](int k0, double(&v)[8]) { load8d<true>(pb + (size_t)k0 * ld, v); });
+            [&](int k0, double(&v)[8]) { load8d_cols(pb + (size_t)k0 * ld, v); });
         double *pc = S + (size_t)bi * TILE * ld + (size_t)bj * TILE;
         tile64_foreach(acc, [&](int r, int c, double v) { pc[(size_t)r * ld + c] = v; });
     } else {
         const double *pa = X + ((size_t)bi * TILE + (t >> 2)) * ld + (t & 3) * 8;
-        const double *pb = S + (size_t)(t >> 3) * ld + (size_t)bj * TILE + (t & 7) * 8;
+        const double *pb = S + (size_t)(t >> 3) * ld + (size_t)bj * TILE + (t & 7) * 2;
         tile64_mac<true>(
             acc, sm, mid * TILE, (bi + 1) * TILE, [&](int k0, double(&v)[8]) { load8d<true>(pa + k0, v); },
-            [&](int k0, double(&v)[8]) { load8d<true>(pb + (size_t)k0 * ld, v); });
+            [&](int k0, double(&v)[8]) { load8d_cols(pb + (size_t)k0 * ld, v); });
         double *pc = X + (size_t)bi * TILE * ld + (size_t)bj * TILE;
         tile64_foreach(acc, [&](int r, int c, double v) { pc[(size_t)r * ld + c] = -v; });
     }

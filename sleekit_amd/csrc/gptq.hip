@@ -650,13 +650,13 @@ __global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, c
     acc.zero();
     const int kend = ka + (kb - ka + KSTEP - 1) / KSTEP * KSTEP;
     const int a_row = r0 + (t >> 2), a_k = (t & 3) * 8;  // A = E (float32), K contiguous
-    const int b_k = t >> 3, b_col = j0 + (t & 7) * 8;    // B = U (float64), columns contiguous
+    const int b_k = t >> 3, b_c2 = (t & 7) * 2;          // B = U (float64), columns contiguous: pieces at 16 h + b_c2
     if (vec_ok && r0 + TILE <= R && j0 + TILE <= jb && kend == kb) {
         const float *pe = Eg + (size_t)a_row * n + a_k;
-        const double *pu = U + (size_t)b_k * n + b_col;
+        const double *pu = U + (size_t)b_k * n + j0 + b_c2;
         tile64_mac<true, float>(
             acc, sm, ka, kend, [&](int k0, float(&v)[8]) { load8f<true>(pe + k0, v); },
-            [&](int k0, double(&v)[8]) { load8d<true>(pu + (size_t)k0 * n, v); });
+            [&](int k0, double(&v)[8]) { load8d_cols(pu + (size_t)k0 * n, v); });
     } else {
         const bool row_ok = a_row < R;
         const float *pe = Eg + (size_t)min(a_row, R - 1) * n;
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, c
             },
             [&](int k0, double(&v)[8]) {
                 const int k = k0 + b_k;
-                load8d_guarded(U + (size_t)min(k, kb - 1) * n + min(b_col, jb - 1), jb - 1 - b_col, k < kb, v);
+                load8d_cols_guarded(U + (size_t)min(k, kb - 1) * n + j0, b_c2, jb - 1 - j0, k < kb, v);
             });
     }
     tile64_foreach(acc, [&](int r, int c, double v) {

@@ -15,7 +15,11 @@
 //
 // Thread -> staged elements (t = threadIdx.x):
 //   A and K-contiguous B : row/col t >> 2,     k = k0 + (t & 3) * 8 + e
-//   column-contiguous B  : k = k0 + (t >> 3),  cols (t & 7) * 8 + e
+//   column-contiguous B  : k = k0 + (t >> 3),  four PIECES of two columns: 16 h + 2 (t & 7) + {0, 1}, h = 0..3
+//     (load8d_cols).  One ds_write_b128 per piece: the 16 lanes of two k rows then cover all 64 banks
+//     (row pitch 80 doubles = 32 banks mod 64).  With 8 consecutive columns per thread the same 16 lanes hit
+//     16 banks four deep -- half of the kernel's LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT) --
+//     and each global load instruction touched 64-byte-strided 16-byte bits instead of 128-byte runs.
 //
 // Operand maps of v_mfma_f64_16x16x4_f64 (guide section 3; exercised with asymmetric data by
 // tests/test_gpu_parity.py::test_factor_of_plain_matrix_and_not_pd):
@@ -64,6 +68,24 @@ __device__ __forceinline__ void load8d(const double *p, double (&v)[8]) {
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = p[e];
+    }
+}
+
+// The column-contiguous B fragment: pieces h = 0..3 at p[16 h], p[16 h + 1] (p already offset by 2 (t & 7)).
+__device__ __forceinline__ void load8d_cols(const double *p, double (&v)[8]) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const double2_t x = *reinterpret_cast<const double2_t *>(p + 16 * h);
+        v[2 * h] = x[0];
+        v[2 * h + 1] = x[1];
+    }
+}
+// ... edge-safe: `row` points at column col0 of the tile, columns beyond `last` (relative) or !ok give zero.
+__device__ __forceinline__ void load8d_cols_guarded(const double *row, int c2, int last, bool ok, double (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int col = 16 * (e >> 1) + c2 + (e & 1);
+        v[e] = row[min(col, max(last, 0))] * ((ok && col <= last) ? 1.0 : 0.0);
     }
 }
 
@@ -124,13 +146,14 @@ __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_beg
     TA ra[8];
     double rb[8];
     double *a_dst = sm.a + (t >> 2) * PITCH_RK + (t & 3) * 8;
-    double *b_dst = B_C_FAST ? sm.b + (t >> 3) * PITCH_KC + (t & 7) * 8 : sm.b + (t >> 2) * PITCH_RK + (t & 3) * 8;
+    double *b_dst = B_C_FAST ? sm.b + (t >> 3) * PITCH_KC + (t & 7) * 2 : sm.b + (t >> 2) * PITCH_RK + (t & 3) * 8;
+    constexpr int B_PIECE = B_C_FAST ? 16 : 2;  // distance between a thread's pieces in the image
 
     auto stash = [&]() {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             *reinterpret_cast<double2_t *>(a_dst + 2 * h) = (double2_t){(double)ra[2 * h], (double)ra[2 * h + 1]};
-            *reinterpret_cast<double2_t *>(b_dst + 2 * h) = (double2_t){rb[2 * h], rb[2 * h + 1]};
+            *reinterpret_cast<double2_t *>(b_dst + B_PIECE * h) = (double2_t){rb[2 * h], rb[2 * h + 1]};
         }
     };
 
@@ -161,6 +184,9 @@ __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_beg
         // operands of group kk + 4 are read from LDS before the MFMAs of group kk are issued
         double a0n = a_src[0], a1n = a_src1[0];
         double b0n = b_src[0], b1n = b_src1[0];
+        // (fence: otherwise these four are fused with the reads of group 4 just below into ds_read2_b64 /
+        // ds_read2st64_b64 -- a quarter of all operand reads, and the remaining bank conflicts)
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int kk = 0; kk < KSTEP; kk += 4) {
             const double a0 = a0n, a1 = a1n, b0 = b0n, b1 = b1n;

@@ -129,4 +129,72 @@ __device__ __forceinline__ void tile128_mac_planes(Acc128 &acc, TileBf16Smem &sm
     }
 }
 
+// ---- the same product with the operands brought to LDS by the memory pipeline itself (global_load_lds_dwordx4).
+// LDS writes are slow (80 bytes a cycle against 256 for reads, profiles/r01_lds_access_microbench.txt): staged through
+// registers a round costs 48 ds_write_b128 a workgroup -- more LDS time than all its operand reads -- and 96 VGPRs
+// of staging (230 -> 122 VGPRs here).  Measured: error GEMM 520 -> 493 us, Hessian accumulation 0.786 -> 0.771 ms; no
+// more, because at 128 x 128 tiles the kernel moves 48 KB from L2 per 6.3 Mflop round -- it runs at the rate the
+// CUs can pull operands out of L2 (32 bytes a cycle and CU), not at the LDS's or the MFMA's.  A slab of k_split3 (128 rows x 32 k of one plane, 8 KB contiguous) is instead copied
+// verbatim, eight 1 KB wave instructions; no padding is possible in such an image, so the planes are stored
+// SWIZZLED: the 16-byte chunk c (of 4) of row r sits at chunk c ^ ((r >> 2) & 3), which makes the operand reads
+// (lane l: row l & 31, chunk (l >> 5) + 2 s) conflict-free -- the eight quads of a half-wave split into two sets of
+// four with disjoint banks.
+struct TileBf16DmaSmem {
+    unsigned char a[3][8192];
+    unsigned char b[3][8192];
+};
+__device__ __forceinline__ int swizzled_chunk(int row, int c) { return c ^ ((row >> 2) & 3); }
+
+// a_slabs / b_slabs: this tile's slab of K-step 0 in plane 0 (consecutive steps 4096 elements apart, planes *_plane apart).
+__device__ __forceinline__ void tile128_mac_dma(Acc128 &acc, TileBf16DmaSmem &sm, int k_begin, int k_end,
+                                                const unsigned short *__restrict__ a_slabs, size_t a_plane,
+                                                const unsigned short *__restrict__ b_slabs, size_t b_plane) {
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    if (k_begin >= k_end) return;
+    // this wave's quarter of a slab: 2 KB = two instructions of 64 lanes x 16 bytes
+    const unsigned short *ga = a_slabs + (size_t)(k_begin >> 5) * 4096 + wave * 1024 + lane * 8;
+    const unsigned short *gb = b_slabs + (size_t)(k_begin >> 5) * 4096 + wave * 1024 + lane * 8;
+    const int sw = ((lane & 31) >> 2) & 3;
+    const int r_off0 = (lane & 31) * 64 + (((lane >> 5) ^ sw) * 16), r_off1 = (lane & 31) * 64 + ((((lane >> 5) + 2) ^ sw) * 16);
+    for (int k0 = k_begin; k0 < k_end; k0 += KB16, ga += 4096, gb += 4096) {
+        __syncthreads();  // the previous round's reads are done
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                __builtin_amdgcn_global_load_lds(ga + p * a_plane + i * 512, sm.a[p] + wave * 2048 + i * 1024, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gb + p * b_plane + i * 512, sm.b[p] + wave * 2048 + i * 1024, 16, 0, 0);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's copies have landed before it passes the barrier
+        __syncthreads();
+        bf16x8_t a[2][2][3], b[2][2][3];  // [s][i][plane]
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[s][i][p] = *reinterpret_cast<const bf16x8_t *>(sm.a[p] + (wr * 64 + i * 32) * 64 + (s ? r_off1 : r_off0));
+                    b[s][i][p] = *reinterpret_cast<const bf16x8_t *>(sm.b[p] + (wc * 64 + i * 32) * 64 + (s ? r_off1 : r_off0));
+                }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float16_t c = acc.c[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][2], b[s][j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][1], b[s][j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][0], b[s][j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][1], b[s][j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][0], b[s][j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][0], b[s][j][0], c, 0, 0, 0);
+                    acc.c[i][j] = c;
+                }
+    }
+}
+
 }  // namespace slk

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
 // would otherwise be split once per tile that uses it (32 times at n = 4096).
 __global__ __launch_bounds__(256) void k_split3(const float *__restrict__ x, const float *__restrict__ y, int rows, int n,
                                                 unsigned short *__restrict__ out, size_t plane,
-                                                const int *__restrict__ sym_flag) {
+                                                const int *__restrict__ sym_flag, int swz) {
     if (sym_flag && sym_flag[0] == 0) return;
     const int ksteps = n / 32;
     const size_t quads = plane / 4;  // groups of four consecutive k
@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void k_split3(const float *__restrict__ x, con
         split3_pair(v[2], v[3], w[0][1], w[1][1], w[2][1]);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            unsigned *o = reinterpret_cast<unsigned *>(out + (size_t)p * plane + e);
+            // (swz: the 16-byte chunk moves inside its row, see tile128_mac_dma)
+            const size_t eo = swz ? (e & ~(size_t)31) + (size_t)(swizzled_chunk(r, k4 >> 3) * 8 + (k4 & 7)) : e;
+            unsigned *o = reinterpret_cast<unsigned *>(out + (size_t)p * plane + eo);
             o[0] = w[p][0];
             o[1] = w[p][1];
         }
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(256) void k_split3(const float *__restrict__ x, con
 // emulated to float32 grade with six bfloat16 terms from operands split by k_split3.  Runs only when the
 // device-side flag says H is symmetric (its rows then serve as the K-contiguous B operand) -- the float32
 // kernel above takes the other case; each returns at once when the flag is not its own.  n % 128 == 0.
+template <bool DMA>
 __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restrict__ W, const float *__restrict__ Q,
                                                           const unsigned short *__restrict__ Dp,
                                                           const unsigned short *__restrict__ Hp, int R, int n,
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
                                                           const int *__restrict__ sym_flag, int p_stride, int cb, int rpl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TileBf16Smem &sm = *reinterpret_cast<TileBf16Smem *>(smem_raw);
+    TileBf16DmaSmem &smd = *reinterpret_cast<TileBf16DmaSmem *>(smem_raw);  // DMA: operands copied to LDS by the loads themselves
     __shared__ float rowpart[2][T32];
     // XCD-aware tile order, column-major inside the XCD.  Workgroup i runs on XCD i % 8 (own L2).  XCD x takes
     // the row tiles [x rpx, (x + 1) rpx) (rpx = 4 for a 4096-row layer) and walks the column tiles in the order
@@ -264,8 +268,12 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
     };
     // sum_k D_k H_kj over all k == 2 * sum_{k < j0} + the 128-wide diagonal band (see k_error_tiles)
     const int k_lo = blk_lo * T32, k_below = min(blk_hi * T32, j0);  // [k_lo, k_below) lies under the band: twice
+    const unsigned short *a_slabs = Dp + (size_t)tile_y * ksteps * 4096, *b_slabs = Hp + (size_t)tile_x * ksteps * 4096;
     if (k_below > k_lo) {
-        tile128_mac_planes(acc, sm, k_lo, k_below, la, lb);
+        if (DMA)
+            tile128_mac_dma(acc, smd, k_lo, k_below, a_slabs, d_plane, b_slabs, h_plane);
+        else
+            tile128_mac_planes(acc, sm, k_lo, k_below, la, lb);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -274,7 +282,12 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
                 for (int r = 0; r < 16; ++r) acc.c[i][j][r] = acc.c[i][j][r] * 2.0f;
         __syncthreads();
     }
-    if (blk_hi == tile_x + 1) tile128_mac_planes(acc, sm, j0, j0 + T32, la, lb);
+    if (blk_hi == tile_x + 1) {
+        if (DMA)
+            tile128_mac_dma(acc, smd, j0, j0 + T32, a_slabs, d_plane, b_slabs, h_plane);
+        else
+            tile128_mac_planes(acc, sm, j0, j0 + T32, la, lb);
+    }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(256) void k_hessian_tiles(float *__restrict__ H, co
 // (128-feature block ib, 32-token step ks) is [feature in block][32 tokens], contiguous; tokens beyond T are
 // zero.  One workgroup per slab: 32 coalesced rows of 128 floats in, through LDS, 8 KB per plane out.
 __global__ __launch_bounds__(256) void k_split3_transposed(const float *__restrict__ X, int n, int T, int t_first, int t_count,
-                                                           unsigned short *__restrict__ out, size_t plane) {
+                                                           unsigned short *__restrict__ out, size_t plane, int swz) {
     __shared__ float tile[32][T32 + 1];
     const int ib = blockIdx.x, ks = blockIdx.y;
     const int t = threadIdx.x;
@@ -425,17 +438,20 @@ __global__ __launch_bounds__(256) void k_split3_transposed(const float *__restri
     unsigned w[3][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) split3_pair(tile[half + 2 * e][ii], tile[half + 2 * e + 1][ii], w[0][e], w[1][e], w[2][e]);
-    const size_t slab = ((size_t)ib * gridDim.y + ks) * 4096 + (size_t)t * 16;
+    const size_t slab = ((size_t)ib * gridDim.y + ks) * 4096 + (size_t)ii * 32;
+    const int c0 = (t & 1) * 2;  // this thread's two 16-byte chunks of the row
+    const int p0 = swz ? swizzled_chunk(ii, c0) : c0, p1 = swz ? swizzled_chunk(ii, c0 + 1) : c0 + 1;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        uint4v_t *o = reinterpret_cast<uint4v_t *>(out + p * plane + slab);
-        o[0] = (uint4v_t){w[p][0], w[p][1], w[p][2], w[p][3]};
-        o[1] = (uint4v_t){w[p][4], w[p][5], w[p][6], w[p][7]};
+        unsigned short *o = out + p * plane + slab;
+        *reinterpret_cast<uint4v_t *>(o + p0 * 8) = (uint4v_t){w[p][0], w[p][1], w[p][2], w[p][3]};
+        *reinterpret_cast<uint4v_t *>(o + p1 * 8) = (uint4v_t){w[p][4], w[p][5], w[p][6], w[p][7]};
     }
 }
 
 // Lower tiles of X^T X on the bfloat16 MFMA (mfma_bf16x3.h), from the planes of k_split3_transposed; same
 // epilogue as k_hessian_tiles.  Tiles of the lower triangle in an XCD-aware order (see k_syrk_triangle).
+template <bool DMA>
 __global__ __launch_bounds__(256) void k_hessian_tiles_bf16(float *__restrict__ H, const unsigned short *__restrict__ Xp, int n,
                                                             int ksteps, size_t plane, float factor, float count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -466,7 +482,11 @@ __global__ __launch_bounds__(256) void k_hessian_tiles_bf16(float *__restrict__ 
 #pragma unroll
             for (int h = 0; h < 2; ++h) v[p][h] = *reinterpret_cast<const uint4v_t *>(q + p * plane + 8 * h);
     };
-    tile128_mac_planes(acc, sm, 0, ksteps * 32, la, lb);
+    if (DMA)
+        tile128_mac_dma(acc, *reinterpret_cast<TileBf16DmaSmem *>(smem_raw), 0, ksteps * 32, Xp + (size_t)bi * ksteps * 4096, plane,
+                        Xp + (size_t)bj * ksteps * 4096, plane);
+    else
+        tile128_mac_planes(acc, sm, 0, ksteps * 32, la, lb);
     const int i0 = bi * T32, j0 = bj * T32;
     tile128_foreach(acc, [&](int r, int c, float v) {
         const int i = i0 + r, j = j0 + c;
@@ -550,21 +570,29 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     if (bf16_ok) {
         static bool attr_set = false;
         if (!attr_set) {
-            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_error_tiles_bf16),
+            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_error_tiles_bf16<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TileBf16Smem)));
+            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_error_tiles_bf16<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TileBf16DmaSmem)));
             attr_set = true;
         }
+        const int dma = getenv("SLK_NO_BF16_DMA") == nullptr;  // operands to LDS by global_load_lds (swizzled planes)
         SLK_RUN("error_split", 0, 14.0 * R * n, s,
-                k_split3<<<2048, 256, 0, s>>>(W, Q, R, n, Dp, d_plane, batch == 1 ? sym : nullptr));
+                k_split3<<<2048, 256, 0, s>>>(W, Q, R, n, Dp, d_plane, batch == 1 ? sym : nullptr, dma));
         for (int b = 0; b < batch; ++b)
             SLK_RUN("error_split", 0, 10.0 * n * n, s,
-                    k_split3<<<2048, 256, 0, s>>>(Hs[b], nullptr, n, n, Hp + (size_t)b * 3 * n * n, (size_t)n * n, sym + b));
+                    k_split3<<<2048, 256, 0, s>>>(Hs[b], nullptr, n, n, Hp + (size_t)b * 3 * n * n, (size_t)n * n, sym + b, dma));
         // flops as executed: six bfloat16 products per float32 product, over k <= j only (the definition of the
         // layer error, SURVEY.md 8d, counts 2 R n^2 float32 flops: a third of this, twice over)
         const int wgs = cb > 0 ? n_rt * n_slots : 8 * ((n_rt + 7) / 8) * ((n_tiles + 7) / 8 * 8);  // see the tile order in the kernel
-        SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, cb > 0 ? wgs : n_rt * n_tiles, s,
-                  k_error_tiles_bf16<<<wgs, 256, sizeof(TileBf16Smem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym, n_slots, cb,
-                                                                            batch == 1 ? R : rpl));
+        if (dma)
+            SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, cb > 0 ? wgs : n_rt * n_tiles, s,
+                      k_error_tiles_bf16<true><<<wgs, 256, sizeof(TileBf16DmaSmem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym, n_slots,
+                                                                                         cb, rpl));
+        else
+            SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, cb > 0 ? wgs : n_rt * n_tiles, s,
+                      k_error_tiles_bf16<false><<<wgs, 256, sizeof(TileBf16Smem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym, n_slots,
+                                                                                        cb, rpl));
         for (int b = 0; b < batch; ++b) SLK_RUN("error_gemm_f32", 0, 0, s, f32_layer(b, sym + b, 1));
     } else {
         for (int b = 0; b < batch; ++b)
@@ -605,10 +633,13 @@ int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, 
     if (n % T32 == 0 && room >= 32 && getenv("SLK_NO_BF16_HESSIAN") == nullptr) {
         static bool attr_set = false;
         if (!attr_set) {
-            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hessian_tiles_bf16),
+            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hessian_tiles_bf16<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TileBf16Smem)));
+            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hessian_tiles_bf16<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TileBf16DmaSmem)));
             attr_set = true;
         }
+        const int dma = getenv("SLK_NO_BF16_DMA") == nullptr;
         const int chunk = (int)(room < (size_t)((T + 31) / 32 * 32) ? room : (size_t)((T + 31) / 32 * 32));
         unsigned short *Xp = ws.take<unsigned short>((size_t)3 * n * chunk);
         const int m = n / T32, total = m * (m + 1) / 2;
@@ -616,11 +647,16 @@ int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, 
             const int cnt = T - t0 < chunk ? T - t0 : chunk, ksteps = (cnt + 31) / 32;
             const size_t plane = (size_t)n * ksteps * 32;
             SLK_RUN("hessian_split", 0, 10.0 * cnt * n, s,
-                    k_split3_transposed<<<dim3(m, ksteps), 256, 0, s>>>(X, n, T, t0, cnt, Xp, plane));
+                    k_split3_transposed<<<dim3(m, ksteps), 256, 0, s>>>(X, n, T, t0, cnt, Xp, plane, dma));
             // the running-mean factor applies once per batch: later chunks add to what the first one scaled
-            SLK_RUN("hessian_syrk_bf16", 6.0 * cnt * n * (n + (double)T32), 6.0 * cnt * n + 8.0 * n * n, s,
-                    k_hessian_tiles_bf16<<<8 * ((total + 7) / 8), 256, sizeof(TileBf16Smem), s>>>(H, Xp, n, ksteps, plane,
-                                                                                                  t0 == 0 ? factor : 1.0f, count));
+            if (dma)
+                SLK_RUN("hessian_syrk_bf16", 6.0 * cnt * n * (n + (double)T32), 6.0 * cnt * n + 8.0 * n * n, s,
+                        k_hessian_tiles_bf16<true><<<8 * ((total + 7) / 8), 256, sizeof(TileBf16DmaSmem), s>>>(
+                            H, Xp, n, ksteps, plane, t0 == 0 ? factor : 1.0f, count));
+            else
+                SLK_RUN("hessian_syrk_bf16", 6.0 * cnt * n * (n + (double)T32), 6.0 * cnt * n + 8.0 * n * n, s,
+                        k_hessian_tiles_bf16<false><<<8 * ((total + 7) / 8), 256, sizeof(TileBf16Smem), s>>>(
+                            H, Xp, n, ksteps, plane, t0 == 0 ? factor : 1.0f, count));
         }
         return SLK_OK;
     }

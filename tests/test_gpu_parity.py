@@ -330,11 +330,15 @@ def test_orders_from_the_inverse_diagonal(amd, order):
         assert np.array_equal(got, want), (order, n)
 
 
-def test_hessian_accumulate_bf16_path(amd):
+@pytest.mark.parametrize("staged", [False, True])
+def test_hessian_accumulate_bf16_path(amd, monkeypatch, staged):
     """statistics.py:76-87 with a feature count that is a multiple of 128: X^T X on the bfloat16 MFMA (three
     pieces per operand).  A ragged token count, two batches (running-mean factor), and a workspace so small
-    that the tokens go in chunks of 32 -- each against float64, to float32 GEMM tolerance."""
+    that the tokens go in chunks of 32 -- each against float64, to float32 GEMM tolerance.  Both ways of bringing
+    the operands to LDS: global_load_lds of swizzled planes (default) and staging through registers."""
     import torch
+    if staged:
+        monkeypatch.setenv("SLK_NO_BF16_DMA", "1")
     from sleekit_amd import _lib, _device as dev
 
     rng = np.random.default_rng(21)
@@ -396,6 +400,9 @@ def test_layer_error_bf16_path(amd, monkeypatch):
     want = ((D @ H.astype(np.float64)) * D).sum(axis=1)
     got = amd.obq.channelwise_error(W, Q, H)
     np.testing.assert_allclose(got, want, rtol=1e-5)
+    monkeypatch.setenv("SLK_NO_BF16_DMA", "1")  # operands staged through registers instead of global_load_lds
+    np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, H), got, rtol=2e-6)
+    monkeypatch.delenv("SLK_NO_BF16_DMA")
     monkeypatch.setenv("SLK_NO_BF16_ERROR", "1")
     got32 = amd.obq.channelwise_error(W, Q, H)
     monkeypatch.delenv("SLK_NO_BF16_ERROR")

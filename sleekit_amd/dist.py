@@ -115,7 +115,7 @@ class HipBackend:
 
     # -- a whole round at once: the row shards of the G layers of a round go through every kernel together
     def can_batch(self, round_layers, lo, hi):
-        if self.moves or len(round_layers) < 2 or len(round_layers) > 64 or (hi - lo) % 128 != 0 or hi == lo:
+        if len(round_layers) < 2 or len(round_layers) > 64 or (hi - lo) % 128 != 0 or hi == lo:
             return False
         first = round_layers[0]
         scaled = first.get("scale") is not None
@@ -141,7 +141,18 @@ class HipBackend:
         W = torch.stack([lay["W"][lo:hi] for lay in round_layers])
         sc = torch.stack([lay["scale"][lo:hi] for lay in round_layers]) if round_layers[0].get("scale") is not None else None
         cb = eng.require_uniform(self.quantizer)
-        Q, idx = eng.run_loop_batch(W, sc, order, U, cb, 32, 8, unscale=sc is not None)
+        if self.moves > 0:
+            # local search works in the scaled domain (engine.quantize_layer): scaled copy in, one search per layer
+            # (a workgroup per row each: already wide), de-scale on the way out
+            R = hi - lo
+            Ws = eng.rows_divide(W.view(B * R, n), sc.reshape(-1)).view(B, R, n) if sc is not None else W
+            Q, idx = eng.run_loop_batch(Ws, None, order, U, cb, 32, 8)
+            for b, lay in enumerate(round_layers):
+                eng.local_search(Ws[b], Q[b], lay["H"], cb, self.moves, idx[b])
+            if sc is not None:
+                Q = eng.rows_divide(Q.view(B * R, n), sc.reshape(-1), invert=True).view(B, R, n)
+        else:
+            Q, idx = eng.run_loop_batch(W, sc, order, U, cb, 32, 8, unscale=sc is not None)
         err = eng.row_errors_batch(W, Q, [lay["H"] for lay in round_layers]) if self.with_error else None
         return [dict(Q=Q[b], idx=idx[b], row_err=None if err is None else err[b], rows=(lo, hi), info=info[b:b + 1])
                 for b in range(B)]

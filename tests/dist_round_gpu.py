@@ -1,7 +1,7 @@
 """Helper of test_gpu_parity.py::test_batched_rounds_two_ranks_one_gpu (launched by torch.distributed.run, 2 ranks).
 
 Both ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one GPU): the row shards of a round's
-layers go through the batched loop (HipBackend.run_round) and must equal, bit for bit, the rows of the
+layers go through the batched loop (HipBackend.run_round; also with local-search moves) and must equal, bit for bit, the rows of the
 unsharded single-GPU result; a ragged layer and a lone last layer take the layer-by-layer route in the same call.
 """
 
@@ -32,8 +32,8 @@ def main():
     layers[1]["H"] = layers[1]["H"].clone()
     layers[1]["H"][2, 5] += 0.125  # not symmetric: that layer's error takes the float32 kernel inside the batch
     calls = {"round": 0, "rows": 0}
-    for overlap in ((2, 2), False):
-        backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True, overlap=overlap)
+    for overlap, moves in (((2, 2), 0), (False, 0), ((2, 2), 6)):
+        backend = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=overlap)
         run_round, run_rows = backend.run_round, backend.run_rows
         backend.run_round = lambda *a: (calls.__setitem__("round", calls["round"] + 1), run_round(*a))[1]
         backend.run_rows = lambda *a: (calls.__setitem__("rows", calls["rows"] + 1), run_rows(*a))[1]
@@ -42,13 +42,13 @@ def main():
         for lay, sh in zip(layers, shards):
             lo, hi = sh["rows"]
             assert (lo, hi) == sdist.row_range(lay["W"].shape[0], rank, size)
-            res = engine.quantize_layer(lay["W"], lay["H"], cb, lay["scale"])
+            res = engine.quantize_layer(lay["W"], lay["H"], cb, lay["scale"], nb_ls_moves=moves)
             err = engine.row_errors(lay["W"], res.Q, lay["H"])
             assert np.array_equal(sh["Q"].cpu().numpy(), res.Q[lo:hi].cpu().numpy())
             assert np.array_equal(sh["idx"].cpu().numpy(), res.idx[lo:hi].cpu().numpy())
             np.testing.assert_allclose(sh["row_err"].cpu().numpy(), err[lo:hi].cpu().numpy(), rtol=1e-5)
             assert int(sh["info"].item()) == 0
-    assert calls["round"] == 2 * 2 and calls["rows"] == 2 * 3, calls  # rounds (0,1), (2,3) batched; (4,5) ragged, (6) alone
+    assert calls["round"] == 3 * 2 and calls["rows"] == 3 * 3, calls  # rounds (0,1), (2,3) batched; (4,5) ragged, (6) alone
     dist.barrier()
     dist.destroy_process_group()
     print(f"DIST_ROUND_OK rank {rank}", flush=True)

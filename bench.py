@@ -196,14 +196,23 @@ def main():
                  "frac": round(frac_of(k), 4), "avg_launch_us": round(1e3 * k["total_ms"] / k["launches"], 2)}
                 for k in sorted(table, key=lambda k: -k["chip_ms"])[:8]
             ]
-        if args.stages and rank == 0:
-            # clean per-kernel table: one more pass on ONE stream (no kernel shares the chip)
+        if world == 1 and table:
+            # the same kernels with the chip to themselves: one more pass on ONE stream.  In the timed region kernels
+            # of several layers share the CUs, which stretches every launch; this is the kernel's own rate.
             _lib.lib.slk_profile_enable(1)
             sdist.quantize_stream(layers, sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=False))
             torch.cuda.synchronize()
             _lib.lib.slk_profile_enable(0)
             seq = _lib.profile_report()
             _lib.lib.slk_profile_reset()
+            alone = next((k for k in seq if k["kernel"] == roofline["kernel"]), None)
+            if alone:
+                a_secs = alone["total_ms"] * 1e-3
+                a_ach = (alone["flops"] / a_secs / 1e12) if roofline["bound"] == "mfma" else (alone["bytes"] / a_secs / 1e9)
+                roofline["alone"] = {"avg_launch_us": round(1e3 * alone["total_ms"] / alone["launches"], 2),
+                                     "achieved": round(a_ach, 3), "frac": round(a_ach / roofline["peak"], 4),
+                                     "note": "single-stream pass after the timed region: no other kernel shares the chip"}
+        if args.stages and rank == 0 and world == 1 and table:
             tot = sum(k["total_ms"] for k in seq)
             print(f"  single-stream pass: {tot:.3f} ms of kernels for {L} layers", file=sys.stderr)
             for k in sorted(seq, key=lambda k: -k["total_ms"]):

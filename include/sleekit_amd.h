@@ -176,7 +176,13 @@ int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n,
 /*     ... of `batch` layers stacked by rows (see slk_gptq_quantize_batch): H is a HOST array of `batch` device
  *     pointers, one n x n Hessian each; batch > 1 needs rows_per_layer % 128 == 0.                          */
 int slk_row_errors_batch(const float *W, const float *Q, const float *const *H, int batch, int rows_per_layer,
-                         int n, float *row_err, void *workspace, size_t ws_bytes, slk_stream_t stream);
+                         int n, const int *symmetric, float *row_err, void *workspace, size_t ws_bytes,
+                         slk_stream_t stream);
+/*     The error of a bit-wise symmetric H takes half the products; the verdict is reached on the device.
+ *     `symmetric` (device, `batch` ints, may be NULL = checked inside): verdicts from slk_symmetry_flag, so that
+ *     ranks sharing a Hessian check it once (the factor's root) instead of once each.  flag[0] = 1 iff
+ *     H[i][j] == H[j][i] bit for bit.                                                                   */
+int slk_symmetry_flag(const float *H, int n, int *flag, slk_stream_t stream);
 
 /* a12+a13 quantize_local_search  (sleekit/obq.py:220-358)
  *     W, Q: R x n float32 in the scaled domain; Q is updated in place, idx

@@ -514,7 +514,7 @@ using namespace slk;
 extern "C" {
 
 static int row_errors_impl(const float *W, const float *Q, const float *const *Hs, int batch, int rpl, int n, float *row_err,
-                           float *G, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+                           float *G, void *workspace, size_t ws_bytes, slk_stream_t stream, const int *sym_known = nullptr) {
     const int R = batch * rpl;
     const int n_tiles = (n + T32 - 1) / T32;
     Arena ws(workspace, ws_bytes);
@@ -546,7 +546,9 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     for (int b = 0; b < batch; ++b) aligned = aligned && (uintptr_t)Hs[b] % 16 == 0;
     const int vec_ok = n % 4 == 0 && aligned;
     const bool try_sym = G == nullptr && getenv("SLK_NO_SYM_ERROR") == nullptr;
-    if (try_sym) {
+    if (try_sym && sym_known) {
+        sym = const_cast<int *>(sym_known);  // verdicts computed elsewhere (slk_symmetry_flag), read only from here on
+    } else if (try_sym) {
         SLK_RUN("set_flag", 0, 4, s, k_set_flag<<<1, 64, 0, s>>>(sym, 1, batch));
         const int t64 = (n + 63) / 64;
         for (int b = 0; b < batch; ++b)
@@ -610,12 +612,21 @@ int slk_row_errors(const float *W, const float *Q, const float *H, int R, int n,
 }
 
 int slk_row_errors_batch(const float *W, const float *Q, const float *const *H, int batch, int rows_per_layer, int n,
-                         float *row_err, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+                         const int *symmetric, float *row_err, void *workspace, size_t ws_bytes, slk_stream_t stream) {
     SLK_REQUIRE(W && Q && H && row_err && rows_per_layer > 0 && n > 0, "bad arguments");
     SLK_REQUIRE(batch >= 1 && batch <= 64, "batch must be 1..64");
     SLK_REQUIRE(batch == 1 || rows_per_layer % T32 == 0, "a batch needs rows_per_layer to be a multiple of 128");
     for (int b = 0; b < batch; ++b) SLK_REQUIRE(H[b], "null Hessian in the batch");
-    return row_errors_impl(W, Q, H, batch, rows_per_layer, n, row_err, nullptr, workspace, ws_bytes, stream);
+    return row_errors_impl(W, Q, H, batch, rows_per_layer, n, row_err, nullptr, workspace, ws_bytes, stream, symmetric);
+}
+
+int slk_symmetry_flag(const float *H, int n, int *flag, slk_stream_t stream) {
+    SLK_REQUIRE(H && flag && n > 0, "bad arguments");
+    hipStream_t s = as_stream(stream);
+    const int t64 = (n + 63) / 64;
+    SLK_RUN("set_flag", 0, 4, s, k_set_flag<<<1, 64, 0, s>>>(flag, 1, 1));
+    SLK_RUN("symmetry_check", 0, 4.0 * n * n, s, k_symmetry_flag<<<t64 * (t64 + 1) / 2, 256, 0, s>>>(H, n, flag));
+    return SLK_OK;
 }
 
 int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, long long count_before,

@@ -62,9 +62,10 @@ class HipBackend:
         return self._streams
 
     def payload_words(self, n):
+        """slk_factor_pack's words, plus one: whether H is bit-wise symmetric (the root checks it once for all ranks)."""
         from . import _lib
 
-        return int(_lib.lib.slk_factor_payload_words(n))
+        return int(_lib.lib.slk_factor_payload_words(n)) + 1
 
     def alloc_payload(self, words, device):
         return torch.empty(words, dtype=torch.int64, device=device)
@@ -75,10 +76,15 @@ class HipBackend:
         from . import _device as dev
         from . import _lib
 
-        order, U, info = factor
+        order, U, info = factor[:3]
         n = U.shape[0]
         payload = self.alloc_payload(words, U.device)
         _lib.check(_lib.lib.slk_factor_pack(dev.ptr(U), dev.ptr(order), dev.ptr(info), n, dev.ptr(payload), dev.stream_handle()))
+        mark = self.payload_words(n) - 1
+        if len(factor) > 3:
+            payload[mark:mark + 1].copy_(factor[3])  # int32 -> int64 on the way
+        else:
+            payload[mark:mark + 1].fill_(-1)  # not checked by the root
         return payload
 
     def unpack(self, payload, n):
@@ -102,13 +108,16 @@ class HipBackend:
             cb = eng.require_uniform(self.quantizer)
             Ws = eng.rows_divide(W, layer["scale"]) if layer.get("scale") is not None else W
             miss = eng.column_miss(Ws, cb, mode == 3)
-        return eng.factorize(H, n, self.damp, mode, miss)
+        factor = eng.factorize(H, n, self.damp, mode, miss)
+        if self.with_error:  # the layer error wants to know whether H is symmetric: decided here, once per layer
+            factor = factor + (eng.symmetry_flag(H),)
+        return factor
 
     def run_rows(self, layer, lo, hi, factor):
         eng = self.engine
         W = layer["W"][lo:hi].contiguous()
         sc = layer["scale"][lo:hi].contiguous() if layer.get("scale") is not None else None
-        res = eng.quantize_layer(W, layer["H"], self.quantizer, sc, self.act_order, self.damp, self.moves, factor=factor)
+        res = eng.quantize_layer(W, layer["H"], self.quantizer, sc, self.act_order, self.damp, self.moves, factor=factor[:3])
         err = eng.row_errors(W, res.Q, layer["H"]) if self.with_error else None
         return dict(Q=res.Q, idx=res.idx, row_err=err, rows=(lo, hi))
 
@@ -153,7 +162,12 @@ class HipBackend:
                 Q = eng.rows_divide(Q.view(B * R, n), sc.reshape(-1), invert=True).view(B, R, n)
         else:
             Q, idx = eng.run_loop_batch(W, sc, order, U, cb, 32, 8, unscale=sc is not None)
-        err = eng.row_errors_batch(W, Q, [lay["H"] for lay in round_layers]) if self.with_error else None
+        err = None
+        if self.with_error:
+            mark = self.payload_words(n) - 1
+            # (every rank runs the same backend settings, so with_error here means the roots packed real verdicts)
+            known = torch.stack([p[mark] for p in payloads]).to(torch.int32)
+            err = eng.row_errors_batch(W, Q, [lay["H"] for lay in round_layers], known)
         return [dict(Q=Q[b], idx=idx[b], row_err=None if err is None else err[b], rows=(lo, hi), info=info[b:b + 1])
                 for b in range(B)]
 

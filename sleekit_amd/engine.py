@@ -151,19 +151,29 @@ def run_loop_batch(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=T
     return Q, idx
 
 
-def row_errors_batch(W, Q, Hs):
-    """Row errors of a batch of layers stacked by rows: W, Q (B, R, n); Hs a list of B (n, n) float32 tensors."""
+def row_errors_batch(W, Q, Hs, symmetric=None):
+    """Row errors of a batch of layers stacked by rows: W, Q (B, R, n); Hs a list of B (n, n) float32 tensors.
+    symmetric: (B,) int32 verdicts of symmetry_flag (None: checked here)."""
     import ctypes
 
     B, R, n = W.shape
     assert len(Hs) == B and W.is_contiguous() and Q.is_contiguous()
+    assert symmetric is None or (symmetric.dtype == torch.int32 and symmetric.numel() == B and symmetric.is_contiguous())
     ws, ws_bytes = dev.workspace(R, n, batch=B)
     out = torch.empty((B, R), dtype=torch.float32, device=W.device)
     ptrs = (ctypes.c_void_p * B)(*[dev.ptr(H) for H in Hs])
     _lib.check(
-        _lib.lib.slk_row_errors_batch(dev.ptr(W), dev.ptr(Q), ptrs, B, R, n, dev.ptr(out), dev.ptr(ws), ws_bytes, dev.stream_handle())
+        _lib.lib.slk_row_errors_batch(dev.ptr(W), dev.ptr(Q), ptrs, B, R, n, dev.ptr(symmetric), dev.ptr(out), dev.ptr(ws), ws_bytes,
+                                      dev.stream_handle())
     )
     return out
+
+
+def symmetry_flag(H):
+    """int32[1] on the device: 1 iff H is bit-wise symmetric (what lets the layer error skip half its products)."""
+    flag = torch.empty(1, dtype=torch.int32, device=H.device)
+    _lib.check(_lib.lib.slk_symmetry_flag(dev.ptr(H), H.shape[0], dev.ptr(flag), dev.stream_handle()))
+    return flag
 
 
 def local_search(W, Q, H, cb_abi, moves, idx=None):

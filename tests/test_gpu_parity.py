@@ -736,6 +736,9 @@ def test_batch_entry_points(amd, B, R, n):
             assert torch.equal(Q[b], q1) and torch.equal(idx[b], i1), (b, unscale)
     Q, _ = eng.run_loop_batch(W, sc, order, U, abi, 32, 8, unscale=True)
     err = eng.row_errors_batch(W, Q, Hs)
+    flags = torch.cat([eng.symmetry_flag(H) for H in Hs])
+    assert flags.tolist() == [1] * (B - 1) + [0]
+    assert torch.equal(eng.row_errors_batch(W, Q, Hs, flags), err)  # verdicts handed in: same route, same sums
     for b in range(B):
         want = ((W[b] - Q[b]).double() @ Hs[b].double() * (W[b] - Q[b]).double()).sum(dim=1)
         np.testing.assert_allclose(err[b].cpu().numpy(), want.cpu().numpy(), rtol=1e-5)

@@ -35,7 +35,7 @@ def main():
         base.append({k: torch.from_numpy(lay[k]).to(device) for k in ("W", "H", "scale")})
     layers = [base[i % 2] for i in range(L)]
     for N in Ns:
-        nl = int(os.environ.get("NL", "0")) or (2 if N == 1 else min(8, 2 * N))
+        nl = int(os.environ.get("NL", "0")) or 2  # bench.py's default
         nf = int(os.environ.get("NF", "3"))
         backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True, overlap=(nf, nl))
         fstreams, cstream, lstreams = backend.streams()
@@ -69,14 +69,16 @@ def main():
             mine = list(range(0, L, N))
             payloads = {}
             if N > 1:
+                cevs = {}
                 with torch.cuda.stream(cstream):
                     for l in mine:
                         cstream.wait_event(evs[l])
                         payloads[l] = backend.pack(facs[l], words)
                         for t in facs[l]:
                             t.record_stream(cstream)
-                    cev = torch.cuda.Event()
-                    cev.record(cstream)
+                        cevs[l] = torch.cuda.Event()  # one hand-over per round, like the all-gather of that round
+                        cevs[l].record(cstream)
+                cev = cevs[mine[-1]]
             out = []
             if N > 1 and os.environ.get("BATCH", "1") != "0":
                 # round by round through the batched loop, as sleekit_amd.dist does (own payload stands in for the peers')
@@ -85,7 +87,7 @@ def main():
                     backend._lrot = (rot + 1) % len(lstreams)
                     ls = lstreams[rot]
                     with torch.cuda.stream(ls):
-                        ls.wait_event(cev)
+                        ls.wait_event(cevs[mine[g]])
                         members = list(range(g * N, (g + 1) * N))
                         out.extend(backend.run_round([layers[l] for l in members], lo, hi, [payloads[mine[g]]] * N))
                         payloads[mine[g]].record_stream(ls)

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
     // H symmetric (checked bit-wise on the device) and G not wanted:
     //   sum_k D_k H_kj over all k  ==  2 * sum_{k < j0} + the 128-wide diagonal band, after the
     //   final multiplication by D_j and the sum over j.  Halves the flops of the layer error.
-    const bool sym = sym_flag != nullptr && sym_flag[0] != 0;
+    const bool sym = sym_flag != nullptr && sym_flag[0] > 0;  // (a negative verdict = unknown: the general route)
     if (sym && bf16_takes_sym) return;
     const int kend = sym ? min(j0 + T32, kfull) : kfull;
     const int ksplit = sym ? j0 : 0;  // [0, ksplit) counted twice
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
 __global__ __launch_bounds__(256) void k_split3(const float *__restrict__ x, const float *__restrict__ y, int rows, int n,
                                                 unsigned short *__restrict__ out, size_t plane,
                                                 const int *__restrict__ sym_flag, int swz) {
-    if (sym_flag && sym_flag[0] == 0) return;
+    if (sym_flag && sym_flag[0] <= 0) return;
     const int ksteps = n / 32;
     const size_t quads = plane / 4;  // groups of four consecutive k
     for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (size_t)gridDim.x * blockDim.x) {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
     const int r0 = tile_y * T32, j0 = tile_x * T32;
     // a batch of layers stacked by rows (rpl rows each, a multiple of the tile): layer b has its own flag and planes of H
     const int layer = r0 / rpl;
-    if (sym_flag[layer] == 0) return;
+    if (sym_flag[layer] <= 0) return;
     Hp += (size_t)layer * 3 * n * n;
     const int t = threadIdx.x;
     Acc128 acc;

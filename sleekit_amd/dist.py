@@ -95,7 +95,8 @@ class HipBackend:
         U = torch.empty((n, n), dtype=torch.float64, device=payload.device)
         info = torch.empty(1, dtype=torch.int32, device=payload.device)
         _lib.check(_lib.lib.slk_factor_unpack(dev.ptr(payload), n, dev.ptr(U), dev.ptr(order), dev.ptr(info), dev.stream_handle()))
-        return order, U, info
+        mark = self.payload_words(n) - 1
+        return order, U, info, payload[mark:mark + 1].to(torch.int32)  # + the root's symmetry verdict (-1: none)
 
     def factorize(self, layer):
         eng = self.engine
@@ -118,7 +119,11 @@ class HipBackend:
         W = layer["W"][lo:hi].contiguous()
         sc = layer["scale"][lo:hi].contiguous() if layer.get("scale") is not None else None
         res = eng.quantize_layer(W, layer["H"], self.quantizer, sc, self.act_order, self.damp, self.moves, factor=factor[:3])
-        err = eng.row_errors(W, res.Q, layer["H"]) if self.with_error else None
+        err = None
+        if self.with_error and len(factor) > 3:  # the verdict on H's symmetry came with the factor
+            err = eng.row_errors_batch(W[None], res.Q[None], [layer["H"]], factor[3])[0]
+        elif self.with_error:
+            err = eng.row_errors(W, res.Q, layer["H"])
         return dict(Q=res.Q, idx=res.idx, row_err=err, rows=(lo, hi))
 
 

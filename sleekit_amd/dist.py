@@ -128,8 +128,10 @@ class HipBackend:
 
 
     # -- a whole round at once: the row shards of the G layers of a round go through every kernel together
+    min_batch = 2  # (tests set 1 to send single-layer rounds through run_round as well)
+
     def can_batch(self, round_layers, lo, hi):
-        if len(round_layers) < 2 or len(round_layers) > 64 or (hi - lo) % 128 != 0 or hi == lo:
+        if len(round_layers) < self.min_batch or len(round_layers) > 64 or (hi - lo) % 128 != 0 or hi == lo:
             return False
         first = round_layers[0]
         scaled = first.get("scale") is not None

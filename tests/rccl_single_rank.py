@@ -43,6 +43,28 @@ def main():
                 assert np.array_equal(sh["idx"].cpu().numpy(), idx)
                 assert np.array_equal(sh["Q"].cpu().numpy(), Q)
                 assert int(sh["info"].item()) == 0
+    # the batched-round route (what N > 1 ranks run) over the same RCCL exchange: rounds of one layer, shards of 128-row multiples
+    layers2 = []
+    for i, (R, n) in enumerate(((256, 512), (128, 320), (256, 512))):
+        lay = synth.make_layer(R, n, 177 + i)
+        layers2.append({k: torch.from_numpy(lay[k]).to(device) for k in ("W", "H", "scale")})
+    layers2[1]["H"] = layers2[1]["H"].clone()
+    layers2[1]["H"][0, 3] += 0.5  # asymmetric: the verdict travels with the payload
+    for moves in (0, 4):
+        backend = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=(2, 2))
+        backend.min_batch = 1
+        rounds = []
+        run_round = backend.run_round
+        backend.run_round = lambda *a: (rounds.append(1), run_round(*a))[1]
+        shards = sdist.quantize_stream(layers2, backend)
+        torch.cuda.synchronize()
+        assert len(rounds) == len(layers2)
+        for lay, sh in zip(layers2, shards):
+            res = engine.quantize_layer(lay["W"], lay["H"], cb, lay["scale"], nb_ls_moves=moves)
+            err = engine.row_errors(lay["W"], res.Q, lay["H"])
+            assert np.array_equal(sh["idx"].cpu().numpy(), res.idx.cpu().numpy())
+            assert np.array_equal(sh["Q"].cpu().numpy(), res.Q.cpu().numpy())
+            np.testing.assert_allclose(sh["row_err"].cpu().numpy(), err.cpu().numpy(), rtol=1e-5)
     t = torch.ones(1, device=device)
     dist.all_reduce(t)
     dist.barrier()

@@ -713,11 +713,11 @@ def test_batched_rounds_two_ranks_one_gpu():
     assert out.returncode == 0 and out.stdout.count("DIST_ROUND_OK") == 2, out.stdout[-2000:] + out.stderr[-4000:]
 
 
-@pytest.mark.parametrize("B,R,n", [(3, 128, 320), (2, 256, 1024), (4, 128, 1100)])
-def test_batch_entry_points(amd, B, R, n):
+@pytest.mark.parametrize("B,R,n,levels", [(3, 128, 320, 8), (2, 256, 1024, 8), (4, 128, 1100, 4), (8, 128, 512, "nf4"), (5, 64, 192, 3)])
+def test_batch_entry_points(amd, B, R, n, levels):
     """slk_gptq_quantize_batch / slk_row_errors_batch: B layers stacked by rows == B separate calls."""
     eng = amd.engine
-    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    cb = amd.codebook.Codebook.nf4() if levels == "nf4" else amd.codebook.UniformCodebook(levels, -1, 1)
     abi = eng.require_uniform(cb)
     Ls = [layer(R, n, 5100 + 7 * b + n) for b in range(B)]
     dev_ = torch.device("cuda")
@@ -734,6 +734,10 @@ def test_batch_entry_points(amd, B, R, n):
         for b in range(B):
             q1, i1, _ = eng.run_loop(W[b], None if scale is None else scale[b], facs[b][0], facs[b][1], abi, 32, 8, unscale=unscale)
             assert torch.equal(Q[b], q1) and torch.equal(idx[b], i1), (b, unscale)
+    if R % 128:  # 64-row shards: the loop batches (tiles of 64), the error entry needs 128
+        with pytest.raises(RuntimeError, match="multiple of 128"):
+            eng.row_errors_batch(W, W, Hs)
+        return
     Q, _ = eng.run_loop_batch(W, sc, order, U, abi, 32, 8, unscale=True)
     err = eng.row_errors_batch(W, Q, Hs)
     flags = torch.cat([eng.symmetry_flag(H) for H in Hs])

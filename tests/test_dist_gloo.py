@@ -51,6 +51,36 @@ class FakeBackend:
         return dict(Q=Q, idx=None, row_err=Q.square().sum(dim=1), rows=(lo, hi))
 
 
+class FakeBatchBackend(FakeBackend):
+    """The same stand-in with the batched-round interface of HipBackend (run_round / can_batch)."""
+
+    def __init__(self):
+        super().__init__()
+        self.rounds = []
+
+    def can_batch(self, round_layers, lo, hi):
+        return len(round_layers) >= 2 and hi > lo and all(l["W"].shape == round_layers[0]["W"].shape for l in round_layers)
+
+    def run_round(self, round_layers, lo, hi, payloads):
+        self.rounds.append([int(l["id"]) for l in round_layers])
+        out = []
+        for layer, payload in zip(round_layers, payloads):
+            factor = self.unpack(payload, layer["H"].shape[0])
+            shard = self.run_rows(layer, lo, hi, factor)
+            shard["info"] = factor[2]
+            out.append(shard)
+        return out
+
+
+def make_equal_layers():
+    g = torch.Generator().manual_seed(11)
+    layers = []
+    for i, (R, n) in enumerate([(8, 6), (8, 6), (8, 6), (8, 6), (5, 4), (5, 4), (8, 6)]):
+        A = torch.randn(n, n, generator=g)
+        layers.append(dict(id=torch.tensor(i), W=torch.randn(R, n, generator=g), H=(A @ A.T).float()))
+    return layers
+
+
 def make_layers():
     g = torch.Generator().manual_seed(7)
     layers = []
@@ -71,6 +101,19 @@ def _worker(rank, size, port, q):
         errs = [float(sdist.layer_error(s["row_err"], layers[i]["W"].shape[0])) for i, s in enumerate(shards)]
         # by value (NumPy): a torch tensor travels as a shared-memory handle that dies with this process
         q.put((rank, be.factored, [(s["rows"], s["Q"].numpy().copy()) for s in shards], errs))
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_batched(rank, size, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        layers = make_equal_layers()
+        be = FakeBatchBackend()
+        shards = sdist.quantize_stream(layers, be)
+        q.put((rank, be.rounds, [(s["rows"], s["Q"].numpy().copy(), int(s["info"].item())) for s in shards]))
     finally:
         dist.destroy_process_group()
 
@@ -115,3 +158,28 @@ def test_stream_over_gloo_world2():
         assert torch.equal(torch.cat([torch.from_numpy(q0), torch.from_numpy(q1)]), single[l]["Q"])  # shards == the unsharded result
         want = float(single[l]["row_err"].double().sum() / R)
         assert abs(got[0][3][l] - want) < 1e-9 * abs(want) and got[0][3][l] == got[1][3][l]
+
+
+@pytest.mark.timeout(120)
+def test_batched_rounds_over_gloo_world2():
+    """Rounds whose layers share a shape go through backend.run_round (one call per round, every member's payload
+    from the round's all-gather); the lone last layer goes layer by layer.  Shards == rows of the unsharded result."""
+    single = sdist.quantize_stream(make_equal_layers(), FakeBackend())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_batched, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=90) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank in range(2):
+        assert got[rank][1] == [[0, 1], [2, 3], [4, 5]]  # three batched rounds; layer 6 is a round of one
+    for l, layer in enumerate(make_equal_layers()):
+        R = layer["W"].shape[0]
+        (lo0, hi0), q0, i0 = got[0][2][l]
+        (lo1, hi1), q1, i1 = got[1][2][l]
+        assert (lo0, hi1) == (0, R) and hi0 == lo1 and i0 == 0 and i1 == 0
+        assert torch.equal(torch.cat([torch.from_numpy(q0), torch.from_numpy(q1)]), single[l]["Q"])

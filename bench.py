@@ -106,10 +106,25 @@ def main():
     streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else (3, 2)
     backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=streams)
 
+    in_flight = []  # per enqueued step: events at the tail of its loop streams
+
     def step():
         # join=False: consecutive steps are independent batches, so the next step's factorisations start under
         # this step's loops (the fence below waits for everything before the clock stops)
         shards = sdist.quantize_stream(layers, backend, join=False)
+        # flow control only: the host enqueues a step several times faster than the GPU runs it, and every step in
+        # flight holds its own factors and outputs (2-3 GB); never more than four steps ahead
+        _, _, lstreams = backend.streams()
+        if lstreams:
+            evs = []
+            for st in lstreams:
+                e = torch.cuda.Event()
+                e.record(st)
+                evs.append(e)
+            in_flight.append(evs)
+            if len(in_flight) > 4:
+                for e in in_flight.pop(0):
+                    e.synchronize()
         return shards
 
     def fence():
@@ -130,6 +145,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     dev.raise_pending()
+    peak_hbm = torch.cuda.max_memory_reserved(device)  # after the timed region (at most five steps in flight)
     ms_per_step = 1e3 * elapsed / args.steps
     weights_per_step = float(L) * R * n
     value = weights_per_step / (elapsed / args.steps) / 1e6
@@ -275,6 +291,7 @@ def main():
                             f"act_order=diag, damp=0.01, local-search moves={args.moves}, layer error included",
                 "layers_per_step": L, "rows": R, "cols": n, "row_sharding": f"{world} ranks x {R // world} rows",
                 "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(t_setup, 1),
+                "peak_hbm_gb": round(peak_hbm / 2**30, 2),
                 "streams": {"factor": streams[0], "loop": streams[1]},
             },
             "roofline": roofline, "cpu_baseline": cpu, "layer_error": err0, "hessian_accumulate": hess,

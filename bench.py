@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic layers cycled through the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts (default 3,2)")
+    ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts (default 3,3)")
     ap.add_argument("--stages", action="store_true", help="also print per-kernel timing table to stderr")
     return ap.parse_args()
 
@@ -102,8 +102,8 @@ def main():
         host_layer0 = {k: base[0][k].cpu().numpy() for k in ("W", "H", "scale")}
     t_setup = time.time() - t_setup
 
-    # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: two loop streams still)
-    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else (3, 2)
+    # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: three loop streams here too)
+    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else (3, 3)
     backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=streams)
 
     in_flight = []  # per enqueued step: events at the tail of its loop streams

@@ -35,7 +35,7 @@ def main():
         base.append({k: torch.from_numpy(lay[k]).to(device) for k in ("W", "H", "scale")})
     layers = [base[i % 2] for i in range(L)]
     for N in Ns:
-        nl = int(os.environ.get("NL", "0")) or 2  # bench.py's default
+        nl = int(os.environ.get("NL", "0")) or 3  # bench.py's default
         nf = int(os.environ.get("NF", "3"))
         backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True, overlap=(nf, nl))
         fstreams, cstream, lstreams = backend.streams()

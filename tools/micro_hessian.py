@@ -14,3 +14,10 @@ t0 = time.perf_counter()
 for _ in range(20): run()
 torch.cuda.synchronize()
 print(f"hessian accumulate n={n} T={T}: {(time.perf_counter()-t0)/20*1e3:.3f} ms")
+_lib.lib.slk_profile_reset()
+_lib.lib.slk_profile_enable(1)
+for _ in range(5): run()
+torch.cuda.synchronize()
+_lib.lib.slk_profile_enable(0)
+for k in sorted(_lib.profile_report(), key=lambda k: -k["total_ms"]):
+    print(f"   {k['kernel']:22s} {k['launches'] // 5:3d}/call  avg {1e3 * k['total_ms'] / k['launches']:8.2f} us")

@@ -651,17 +651,22 @@ __global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, c
     const int kend = ka + (kb - ka + KSTEP - 1) / KSTEP * KSTEP;
     const int a_row = r0 + (t >> 2), a_k = (t & 3) * 8;  // A = E (float32), K contiguous
     const int b_k = t >> 3, b_c2 = (t & 7) * 2;          // B = U (float64), columns contiguous: pieces at 16 h + b_c2
-    if (vec_ok && r0 + TILE <= R && j0 + TILE <= jb && kend == kb) {
+    // interior tiles take the unguarded loaders over the whole K-steps; a ragged last step (K = 172 at n = 11008)
+    // and the edge tiles take the guarded ones
+    int k_fast = ka;
+    if (vec_ok && r0 + TILE <= R && j0 + TILE <= jb) {
+        k_fast = ka + (kb - ka) / KSTEP * KSTEP;
         const float *pe = Eg + (size_t)a_row * n + a_k;
         const double *pu = U + (size_t)b_k * n + j0 + b_c2;
         tile64_mac<true, float>(
-            acc, sm, ka, kend, [&](int k0, float(&v)[8]) { load8f<true>(pe + k0, v); },
+            acc, sm, ka, k_fast, [&](int k0, float(&v)[8]) { load8f<true>(pe + k0, v); },
             [&](int k0, double(&v)[8]) { load8d_cols(pu + (size_t)k0 * n, v); });
-    } else {
+    }
+    if (k_fast < kend) {
         const bool row_ok = a_row < R;
         const float *pe = Eg + (size_t)min(a_row, R - 1) * n;
         tile64_mac<true, float>(
-            acc, sm, ka, kend,
+            acc, sm, k_fast, kend,
             [&](int k0, float(&v)[8]) {
                 const int k = k0 + a_k;
                 load8f_guarded(pe + min(k, kb - 1), kb - 1 - k, row_ok, v);

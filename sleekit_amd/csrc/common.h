@@ -145,4 +145,25 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// Zero-fill and copy as plain kernels rather than hipMemsetAsync / hipMemcpyAsync: inside a captured hipGraph the
+// runtime's memset node did not take effect on replay (ROCm 7.2: a counting sort's rank buffer kept the previous
+// replay's counts and the order it produced indexed out of bounds); kernel nodes replay faithfully.
+__global__ __launch_bounds__(256) static void k_zero_words(unsigned *__restrict__ p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+__global__ __launch_bounds__(256) static void k_copy_words(unsigned *__restrict__ dst, const unsigned *__restrict__ src, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// (sizes are multiples of 4 bytes everywhere they are used)
+static inline void zero_async(void *p, size_t bytes, hipStream_t s) {
+    const size_t words = bytes / 4;
+    const int blocks = (int)((words + 1023) / 1024 < 2048 ? (words + 1023) / 1024 : 2048);
+    if (words) k_zero_words<<<blocks ? blocks : 1, 256, 0, s>>>(static_cast<unsigned *>(p), words);
+}
+static inline void copy_async(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    const size_t words = bytes / 4;
+    const int blocks = (int)((words + 1023) / 1024 < 2048 ? (words + 1023) / 1024 : 2048);
+    if (words) k_copy_words<<<blocks ? blocks : 1, 256, 0, s>>>(static_cast<unsigned *>(dst), static_cast<const unsigned *>(src), words);
+}
+
 }  // namespace slk

@@ -970,6 +970,6 @@ extern "C" int slk_gptq_quantize_batch(const float *W, const float *scale, const
         SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out_lds<<<R < 2048 ? R : 2048, 256, (size_t)n * 4, s>>>(Qp, inv_order, R, n, g, unscale ? scale : nullptr, Q, idx, rpl));
     else
         SLK_RUN("permute_out", 0, (idx ? 9.0 : 8.0) * R * n, s, k_permute_out<<<R < 2048 ? R : 2048, 256, 0, s>>>(Qp, inv_order, R, n, g, unscale ? scale : nullptr, Q, idx, rpl));
-    if (E_out) SLK_HIP(hipMemcpyAsync(E_out, Eg, sizeof(float) * (size_t)R * n, hipMemcpyDeviceToDevice, s));
+    if (E_out) copy_async(E_out, Eg, sizeof(float) * (size_t)R * n, s);
     return SLK_OK;
 }

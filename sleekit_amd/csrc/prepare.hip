@@ -400,10 +400,10 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
     SLK_RUN("order_keys", 0, 12.0 * n, s,
             k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, weighted ? miss : nullptr, scal, keys));
     if (order_mode == SLK_ORDER_KEYS)  // caller-supplied float64 sort keys (ascending)
-        SLK_HIP(hipMemcpyAsync(keys, miss, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        copy_async(keys, miss, sizeof(double) * (size_t)n, s);
     const int identity = order_mode == SLK_ORDER_NONE;
     if (!identity) {
-        SLK_HIP(hipMemsetAsync(rank, 0, sizeof(int) * (size_t)n, s));
+        zero_async(rank, sizeof(int) * (size_t)n, s);
         const int slices = 16, slice = (n + slices - 1) / slices;
         SLK_RUN("rank_partial", 0, 16.0 * n, s, k_rank_partial<<<dim3((n + 255) / 256, slices), 256, 0, s>>>(keys, n, slice, rank));
     }

@@ -561,7 +561,7 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
         return SLK_E_WS;
     }
     hipStream_t s = as_stream(stream);
-    if (cb > 0) SLK_HIP(hipMemsetAsync(partial, 0, (size_t)R * n_slots * sizeof(float), s));  // the float32 kernel fills n_tiles slots only
+    if (cb > 0) zero_async(partial, (size_t)R * n_slots * sizeof(float), s);  // the float32 kernel fills n_tiles slots only
     const int rt_layer = (rpl + T32 - 1) / T32;  // row tiles of one layer
     dim3 grid(8 * ((n_tiles * rt_layer + 7) / 8));  // a multiple of the 8 XCDs: see the tile order in the kernel
     bool aligned = ((uintptr_t)W | (uintptr_t)Q) % 16 == 0;

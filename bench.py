@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts (default 3,3)")
     ap.add_argument("--stages", action="store_true", help="also print per-kernel timing table to stderr")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay each layer's pipeline from a hipGraph (one launch per layer): for small, launch-bound layers; N = 1")
     return ap.parse_args()
 
 
@@ -108,7 +110,41 @@ def main():
 
     in_flight = []  # per enqueued step: events at the tail of its loop streams
 
+    graphed, gstreams = [], []
+    if args.graphs:
+        assert world == 1, "--graphs is a single-GPU mode"
+        from sleekit_amd import graphs
+
+        gstreams = [torch.cuda.Stream() for _ in range(sum(streams))]
+        for i, lay in enumerate(layers):
+            # the inputs are resident: the graph reads them in place
+            g = graphs.GraphedLayer(R, n, cb, "diag", 0.01, with_error=True, device=device, inputs=(lay["W"], lay["H"], lay["scale"]))
+            with torch.cuda.stream(gstreams[i % len(gstreams)]):
+                g.capture()
+            graphed.append(g)
+        torch.cuda.synchronize()
+
+    def step_graphs():
+        here = torch.cuda.current_stream()
+        for st in gstreams:
+            st.wait_stream(here)
+        for i, g in enumerate(graphed):
+            with torch.cuda.stream(gstreams[i % len(gstreams)]):
+                g()
+        evs = []
+        for st in gstreams:
+            e = torch.cuda.Event()
+            e.record(st)
+            evs.append(e)
+        in_flight.append(evs)
+        if len(in_flight) > 4:
+            for e in in_flight.pop(0):
+                e.synchronize()
+        return [dict(row_err=g.row_err) for g in graphed]
+
     def step():
+        if args.graphs:
+            return step_graphs()
         # join=False: consecutive steps are independent batches, so the next step's factorisations start under
         # this step's loops (the fence below waits for everything before the clock stops)
         shards = sdist.quantize_stream(layers, backend, join=False)
@@ -302,7 +338,7 @@ def main():
                 "layers_per_step": L, "rows": R, "cols": n, "row_sharding": f"{world} ranks x {R // world} rows",
                 "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(t_setup, 1),
                 "peak_hbm_gb": round(peak_hbm / 2**30, 2),
-                "streams": {"factor": streams[0], "loop": streams[1]},
+                "streams": {"factor": streams[0], "loop": streams[1]}, "hip_graphs": bool(args.graphs),
             },
             "roofline": roofline, "cpu_baseline": cpu, "layer_error": err0, "hessian_accumulate": hess,
         }

@@ -20,13 +20,20 @@ from . import engine
 
 
 class GraphedLayer:
-    def __init__(self, R, n, quantizer, act_order="diag", damp=0.01, scaled=True, with_error=True, device=None):
+    def __init__(self, R, n, quantizer, act_order="diag", damp=0.01, scaled=True, with_error=True, device=None, inputs=None):
+        """inputs = (W, H, scale): resident device tensors the graph shall read IN PLACE (they must hold valid data
+        when the graph is captured: the warm-up run uses them); default: buffers of its own, filled by __call__."""
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.args = (quantizer, act_order, damp)
         self.with_error = with_error
-        self.W = torch.empty((R, n), dtype=torch.float32, device=device)
-        self.H = torch.empty((n, n), dtype=torch.float32, device=device)
-        self.scale = torch.empty(R, dtype=torch.float32, device=device) if scaled else None
+        self._own = inputs is None
+        if inputs is None:
+            self.W = torch.empty((R, n), dtype=torch.float32, device=device)
+            self.H = torch.empty((n, n), dtype=torch.float32, device=device)
+            self.scale = torch.empty(R, dtype=torch.float32, device=device) if scaled else None
+        else:
+            self.W, self.H, self.scale = inputs
+            assert self.W.shape == (R, n) and self.H.shape == (n, n) and self.W.is_contiguous() and self.H.is_contiguous()
         self.graph = None
         self.Q = self.idx = self.row_err = self.info = None
 
@@ -45,11 +52,12 @@ class GraphedLayer:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self.W.zero_()
-                self.H.zero_()
-                self.H.diagonal().fill_(1.0)
-                if self.scale is not None:
-                    self.scale.fill_(1.0)
+                if self._own:  # something harmless to factor
+                    self.W.zero_()
+                    self.H.zero_()
+                    self.H.diagonal().fill_(1.0)
+                    if self.scale is not None:
+                        self.scale.fill_(1.0)
                 self._body()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()

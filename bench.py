@@ -150,10 +150,10 @@ def main():
         shards = sdist.quantize_stream(layers, backend, join=False)
         # flow control only: the host enqueues a step several times faster than the GPU runs it, and every step in
         # flight holds its own factors and outputs (2-3 GB); never more than four steps ahead
-        _, _, lstreams = backend.streams()
+        fstreams, _, lstreams = backend.streams()
         if lstreams:
             evs = []
-            for st in lstreams:
+            for st in lstreams + fstreams:
                 e = torch.cuda.Event()
                 e.record(st)
                 evs.append(e)

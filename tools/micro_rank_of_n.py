@@ -37,7 +37,7 @@ def main():
     for N in Ns:
         nl = int(os.environ.get("NL", "0")) or 3  # bench.py's default
         nf = int(os.environ.get("NF", "3"))
-        backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True, overlap=(nf, nl))
+        backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True, overlap=(nf, nl), queue_aware=N > 1)
         fstreams, cstream, lstreams = backend.streams()
         words = backend.payload_words(n)
         lo, hi = sdist.row_range(R, 0, N)
@@ -86,6 +86,8 @@ def main():
                     rot = getattr(backend, "_lrot", 0)
                     backend._lrot = (rot + 1) % len(lstreams)
                     ls = lstreams[rot]
+                    if os.environ.get("SLOT", "1") != "0":  # (dist.py's default) the round runs on the stream that factored this rank's layer of it
+                        ls = fstreams[(first + g) % len(fstreams)]
                     with torch.cuda.stream(ls):
                         ls.wait_event(cevs[mine[g]])
                         members = list(range(g * N, (g + 1) * N))

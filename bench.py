@@ -33,6 +33,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES in-order hardware queues (4 by default).  On several
+# ranks the pipeline has factor streams, a comm stream and RCCL's own: with 4 queues some of them share one and stop
+# overlapping (one rank's step at N = 8: 4.5 ms with 8 queues, 4.9 ... 7.0 with 4, depending on how the streams fell);
+# on one rank 4 queues measured best (4430 against 3780 Mweights/s with 8).  Must be set before HIP initialises.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 import torch.distributed as dist
 

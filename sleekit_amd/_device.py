@@ -95,59 +95,3 @@ def raise_pending():
     for info, what in pending:
         _raise_if_failed(info, what)
 
-
-_queue_groups = {}
-
-
-def queue_groups(n_probe=12):
-    """Streams grouped by the hardware queue they landed on: [[stream, ...], ...], the default stream's group last.
-
-    HIP multiplexes every stream of a process onto a few in-order hardware queues (GPU_MAX_HW_QUEUES, 4 by default);
-    which streams share one depends on what the runtime created before (torch's pool, RCCL's own streams).  Two
-    streams in one queue do not overlap, whatever the code says -- the factorisation of the next round queued behind
-    this round's loops costs a factor 1.5 at N = 8 -- so the pipeline picks its streams by queue.  Probe: a ~2 ms kernel
-    on stream i, a one-element kernel on every other stream; those that finish after it share its queue.
-    """
-    dev = require_gpu()
-    if dev.index in _queue_groups:
-        return _queue_groups[dev.index]
-    streams = [torch.cuda.Stream(dev) for _ in range(n_probe)]
-    default = torch.cuda.default_stream(dev)
-    everyone = streams + [default]
-    sink = torch.zeros(4096, dtype=torch.float64, device=dev)
-    tick = torch.zeros(len(everyone), 8, dtype=torch.float32, device=dev)
-    for j, st in enumerate(everyone):  # first use of every stream (queues are bound lazily)
-        with torch.cuda.stream(st):
-            tick[j].add_(1.0)
-    torch.cuda.synchronize(dev)
-    group_of = {}
-    groups = []
-    for i, si in enumerate(everyone):
-        if i in group_of:
-            continue
-        members = [i]
-        group_of[i] = len(groups)
-        done = torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(si):
-            _lib.check(_lib.lib.slk_probe_mfma_f64(sink.data_ptr(), 256, 20000, si.cuda_stream))
-            done.record(si)
-        marks = {}
-        for j, sj in enumerate(everyone):
-            if j in group_of:
-                continue
-            e = torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(sj):
-                tick[j].add_(1.0)
-                e.record(sj)
-            marks[j] = e
-        torch.cuda.synchronize(dev)
-        for j, e in marks.items():
-            if done.elapsed_time(e) > -0.2:  # finished after (or within 0.2 ms before the end of) the long kernel
-                members.append(j)
-                group_of[j] = len(groups)
-        groups.append(members)
-    out = [[everyone[j] for j in g if everyone[j] is not default] for g in groups if len(everyone) - 1 not in g]
-    last = [[everyone[j] for j in g if everyone[j] is not default] for g in groups if len(everyone) - 1 in g]
-    out = [g for g in out if g] + [g for g in last if g]
-    _queue_groups[dev.index] = out
-    return out

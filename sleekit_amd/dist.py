@@ -45,14 +45,10 @@ def factor_root(layer_index, size):
 class HipBackend:
     """The real thing: sleekit_amd.engine on the current device."""
 
-    def __init__(self, quantizer, act_order="diag", damp=0.01, nb_ls_moves=0, with_error=True, overlap=True, queue_aware=None):
-        """queue_aware: pick the streams by hardware queue (see _pick_streams); default: on several ranks only -- the
-        exchange and the batched rounds are what a bad pairing of streams hurts (4.3 against 4.9 ... 7.0 ms per step at
-        N = 8); on one rank the plain torch streams measured 2 % faster."""
+    def __init__(self, quantizer, act_order="diag", damp=0.01, nb_ls_moves=0, with_error=True, overlap=True):
         from . import engine
 
         self.engine, self.quantizer, self.overlap = engine, quantizer, overlap
-        self.queue_aware = queue_aware
         self.act_order, self.damp, self.moves, self.with_error = act_order, damp, nb_ls_moves, with_error
 
     def streams(self):
@@ -61,32 +57,9 @@ class HipBackend:
             return None, None, None
         if not hasattr(self, "_streams"):
             nf, nl = (self.overlap if isinstance(self.overlap, tuple) else (2, 2))
-            aware = self.queue_aware if self.queue_aware is not None else world()[1] > 1
-            self._streams = self._pick_streams(nf, nl, aware)
+            self._streams = ([torch.cuda.Stream() for _ in range(nf)], torch.cuda.Stream(),
+                             [torch.cuda.Stream() for _ in range(nl)])
         return self._streams
-
-    @staticmethod
-    def _pick_streams(nf, nl, aware=True):
-        """Streams by hardware queue (_device.queue_groups): factor streams on queues of their own as far as there are
-        queues, the comm stream on the queue of the (idle) default stream, loop streams filling up from there."""
-        from . import _device as dev
-
-        groups = [list(g) for g in dev.queue_groups()] if aware else []  # the default stream's group is last
-        if len(groups) < 2:
-            return ([torch.cuda.Stream() for _ in range(nf)], torch.cuda.Stream(), [torch.cuda.Stream() for _ in range(nl)])
-
-        def take(order):
-            for gi in order:
-                if groups[gi]:
-                    return groups[gi].pop(0)
-            return torch.cuda.Stream()
-
-        q = len(groups)
-        fstreams = [take([(i % max(q - 1, 1)) + 0] + list(range(q))) for i in range(nf)]
-        cstream = take([q - 1] + list(range(q)))
-        # loop streams: the default stream's queue first (nothing else runs there), then the factor queues backwards
-        lstreams = [take([(q - 1 - i) % q] + list(range(q))) for i in range(nl)]
-        return fstreams, cstream, lstreams
 
     def payload_words(self, n):
         """slk_factor_pack's words, plus one: whether H is bit-wise symmetric (the root checks it once for all ranks)."""
@@ -321,11 +294,12 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
             ls = lstreams[batched_rounds % len(lstreams)] if side else None
             own = [l for l in members if l in stream_of]
             if side and own and getattr(backend, "rounds_on_factor_streams", True):
-                # The round runs on the stream that factored this rank's layer of it.  HIP multiplexes all streams onto
-                # four hardware queues, each in order: on a loop stream that happens to share its queue with the factor
-                # stream of the NEXT round, that factorisation sits behind this round's loops and the pipeline collapses
-                # into factor -> loop -> factor (measured: 4.4 or 7.0 ms per step at N = 8 depending on how the streams
-                # fell).  Factor streams + the comm stream are four streams: one queue each.
+                # The round runs on the stream that factored this rank's layer of it: one stream fewer to pair badly.
+                # HIP multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (4 by default) in-order hardware queues;
+                # a loop stream that shares its queue with the factor stream of the NEXT round puts that factorisation
+                # behind this round's loops and the pipeline collapses into factor -> loop -> factor (4.4 ... 7.0 ms per
+                # step at N = 8 depending on how the streams fell).  Multi-rank runs should raise GPU_MAX_HW_QUEUES to 8
+                # before HIP starts (bench.py does): every stream, RCCL's included, then has a queue of its own.
                 ls = stream_of[own[0]]
             batched_rounds += 1
             if side:

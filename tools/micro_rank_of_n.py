@@ -37,7 +37,7 @@ def main():
     for N in Ns:
         nl = int(os.environ.get("NL", "0")) or 3  # bench.py's default
         nf = int(os.environ.get("NF", "3"))
-        backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True, overlap=(nf, nl), queue_aware=N > 1)
+        backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True, overlap=(nf, nl))
         fstreams, cstream, lstreams = backend.streams()
         words = backend.payload_words(n)
         lo, hi = sdist.row_range(R, 0, N)

@@ -117,6 +117,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        host_ms = 1e3 * (time.perf_counter() - t0) / steps  # enqueue only (the GPU is still running)
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / steps
         dev.raise_pending()
@@ -135,7 +136,7 @@ def main():
                 print(f"    {k['kernel']:24s} {k['launches'] // steps:5d} launches/step {k['total_ms'] / steps:8.3f} ms  chip {k['chip_ms'] / steps:7.3f} ms")
             _lib.lib.slk_profile_reset()
         print(f"N={N}: {ms:8.3f} ms per step on one rank  ->  {L * R * n / ms / 1e3:8.0f} Mweights/s whole job "
-              f"(x{(L * R * n / ms / 1e3) / 1:.0f}), payload {words * 8 / 1e6:.0f} MB per layer", flush=True)
+              f"(x{(L * R * n / ms / 1e3) / 1:.0f}), payload {words * 8 / 1e6:.0f} MB per layer; host enqueue {host_ms:.2f} ms per step", flush=True)
 
 
 if __name__ == "__main__":

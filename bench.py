@@ -33,12 +33,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np
-# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES in-order hardware queues (4 by default).  On several
-# ranks the pipeline has factor streams, a comm stream and RCCL's own: with 4 queues some of them share one and stop
-# overlapping (one rank's step at N = 8: 4.5 ms with 8 queues, 4.9 ... 7.0 with 4, depending on how the streams fell);
-# on one rank 4 queues measured best (4430 against 3780 Mweights/s with 8).  Must be set before HIP initialises.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES in-order hardware queues (4 by default): with 3 factor
+# streams, a comm stream, loop streams and RCCL's own, some share a queue and stop overlapping -- a loop stream behind a
+# factor chain, the next round's factorisation behind this round's loops.  With 8 queues every stream has its own:
+# one rank's step at N = 8 takes 4.5 ms instead of 4.9 ... 7.0 (depending on how the streams fell), and on one rank
+# three factor streams + ONE loop stream reach 4720 Mweights/s against 4450 for the best pairing found on 4 queues.
+# Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch
 import torch.distributed as dist
@@ -66,7 +67,7 @@ def parse():
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic layers cycled through the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts (default 3,3)")
+    ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts (default 3,1)")
     ap.add_argument("--stages", action="store_true", help="also print per-kernel timing table to stderr")
     ap.add_argument("--graphs", action="store_true",
                     help="replay each layer's pipeline from a hipGraph (one launch per layer): for small, launch-bound layers; N = 1")
@@ -111,8 +112,8 @@ def main():
         host_layer0 = {k: base[0][k].cpu().numpy() for k in ("W", "H", "scale")}
     t_setup = time.time() - t_setup
 
-    # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: three loop streams here too)
-    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else (3, 3)
+    # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: one loop stream; the batched rounds run on the factor streams)
+    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else (3, 1)
     backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=streams)
 
     in_flight = []  # per enqueued step: events at the tail of its loop streams

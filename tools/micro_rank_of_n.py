@@ -9,6 +9,8 @@ completely behind the loops (an upper bound for bench.py --gpus N).
 """
 
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # as bench.py
 import sys
 import time
 
@@ -35,7 +37,7 @@ def main():
         base.append({k: torch.from_numpy(lay[k]).to(device) for k in ("W", "H", "scale")})
     layers = [base[i % 2] for i in range(L)]
     for N in Ns:
-        nl = int(os.environ.get("NL", "0")) or 3  # bench.py's default
+        nl = int(os.environ.get("NL", "0")) or 1  # bench.py's default
         nf = int(os.environ.get("NF", "3"))
         backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True, overlap=(nf, nl))
         fstreams, cstream, lstreams = backend.streams()

@@ -9,6 +9,12 @@ HIP library is built; everything else needs libsleekit_amd.so and fails loudly w
 """
 
 import importlib
+import os as _os
+
+# Streams only overlap when they sit in different hardware queues, and HIP gives a process 4 of them by default
+# ("Hardware queues"): the pipelines of sleekit_amd.dist and bench.py want a queue per stream.  Read by the
+# HIP runtime when it initialises, so this has no effect once the process has touched the GPU.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _SUBMODULES = ("codebook", "obq", "scaling", "statistics", "engine", "dist", "synth", "_lib", "_device")
 

@@ -38,8 +38,8 @@ import numpy as np
 # factor chain, the next round's factorisation behind this round's loops.  With 8 queues every stream has its own:
 # one rank's step at N = 8 takes 4.5 ms instead of 4.9 ... 7.0 (depending on how the streams fell), and on one rank
 # three factor streams + ONE loop stream reach 4720 Mweights/s against 4450 for the best pairing found on 4 queues.
-# Must be set before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Small layers are the exception: chains of launches of a few microseconds, where 4 queues and more streams measured
+# better (768 x 768: 0.34 ms per layer against 0.43).  Set in main(), before HIP initialises.
 
 import torch
 import torch.distributed as dist
@@ -79,6 +79,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    launch_bound = args.cols <= 1024 and world == 1  # small shapes (see the note on hardware queues at the top)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if launch_bound else "8")
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     dev_index = local_rank % torch.cuda.device_count()  # (a rehearsal may put several ranks on one GPU)
     torch.cuda.set_device(dev_index)
@@ -113,7 +115,7 @@ def main():
     t_setup = time.time() - t_setup
 
     # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: one loop stream; the batched rounds run on the factor streams)
-    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else (3, 1)
+    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else ((3, 3) if launch_bound else (3, 1))
     backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=streams)
 
     in_flight = []  # per enqueued step: events at the tail of its loop streams

@@ -56,7 +56,7 @@ class HipBackend:
         if not self.overlap:
             return None, None, None
         if not hasattr(self, "_streams"):
-            nf, nl = (self.overlap if isinstance(self.overlap, tuple) else (2, 2))
+            nf, nl = (self.overlap if isinstance(self.overlap, tuple) else (3, 1))  # best on 8 hardware queues
             self._streams = ([torch.cuda.Stream() for _ in range(nf)], torch.cuda.Stream(),
                              [torch.cuda.Stream() for _ in range(nl)])
         return self._streams

@@ -118,6 +118,7 @@ size_t slk_workspace_bytes(int R, int n) {
     // layer error on the bfloat16 MFMA: three 2-byte planes of W - Q and of H, the per-tile partial sums
     size_t error = 6 * (rn + 128 * (size_t)n) + 6 * (size_t)n * n + 4 * (size_t)R * ((n + 127) / 128) * sizeof(float) + 8192;
     size_t prep = 64 * sizeof(float) + (size_t)n * (sizeof(double) + 1);
+    search += error;  // the local search calls the layer error (for G = (W - Q) H) behind its own scratch
     size_t m = factor;
     if (loop > m) m = loop;
     if (search > m) m = search;

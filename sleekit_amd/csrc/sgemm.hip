@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
                                                           const unsigned short *__restrict__ Dp,
                                                           const unsigned short *__restrict__ Hp, int R, int n,
                                                           float *__restrict__ partial, int n_tiles,
-                                                          const int *__restrict__ sym_flag, int p_stride, int cb, int rpl) {
+                                                          const int *__restrict__ sym_flag, int p_stride, int cb, int rpl,
+                                                          float *__restrict__ G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TileBf16Smem &sm = *reinterpret_cast<TileBf16Smem *>(smem_raw);
     TileBf16DmaSmem &smd = *reinterpret_cast<TileBf16DmaSmem *>(smem_raw);  // DMA: operands copied to LDS by the loads themselves
@@ -269,7 +270,13 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
     // sum_k D_k H_kj over all k == 2 * sum_{k < j0} + the 128-wide diagonal band (see k_error_tiles)
     const int k_lo = blk_lo * T32, k_below = min(blk_hi * T32, j0);  // [k_lo, k_below) lies under the band: twice
     const unsigned short *a_slabs = Dp + (size_t)tile_y * ksteps * 4096, *b_slabs = Hp + (size_t)tile_x * ksteps * 4096;
-    if (k_below > k_lo) {
+    if (G) {
+        // the product itself is wanted (local search: G = (W - Q) H, obq.py:231): every k, nothing counted twice
+        if (DMA)
+            tile128_mac_dma(acc, smd, 0, n, a_slabs, d_plane, b_slabs, h_plane);
+        else
+            tile128_mac_planes(acc, sm, 0, n, la, lb);
+    } else if (k_below > k_lo) {
         if (DMA)
             tile128_mac_dma(acc, smd, k_lo, k_below, a_slabs, d_plane, b_slabs, h_plane);
         else
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
                 for (int r = 0; r < 16; ++r) acc.c[i][j][r] = acc.c[i][j][r] * 2.0f;
         __syncthreads();
     }
-    if (blk_hi == tile_x + 1) {
+    if (!G && blk_hi == tile_x + 1) {
         if (DMA)
             tile128_mac_dma(acc, smd, j0, j0 + T32, a_slabs, d_plane, b_slabs, h_plane);
         else
@@ -302,6 +309,7 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
                 const int col = j0 + wc * 64 + j * 32 + (lane & 31);
                 if (r0 + row < R) {
                     const size_t o = (size_t)(r0 + row) * n + col;
+                    if (G) G[o] = acc.c[i][j][r];
                     s = s + acc.c[i][j][r] * (W[o] - Q[o]);
                 }
             }
@@ -567,7 +575,7 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     bool aligned = ((uintptr_t)W | (uintptr_t)Q) % 16 == 0;
     for (int b = 0; b < batch; ++b) aligned = aligned && (uintptr_t)Hs[b] % 16 == 0;
     const int vec_ok = n % 4 == 0 && aligned;
-    const bool try_sym = G == nullptr && getenv("SLK_NO_SYM_ERROR") == nullptr;
+    const bool try_sym = getenv("SLK_NO_SYM_ERROR") == nullptr;  // (with G too: the bfloat16 kernel needs H symmetric)
     if (try_sym && sym_known) {
         sym = const_cast<int *>(sym_known);  // verdicts computed elsewhere (slk_symmetry_flag), read only from here on
     } else if (try_sym) {
@@ -612,16 +620,16 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
         if (dma)
             SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, cb > 0 ? wgs : n_rt * n_tiles, s,
                       k_error_tiles_bf16<true><<<wgs, 256, sizeof(TileBf16DmaSmem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym, n_slots,
-                                                                                         cb, rpl));
+                                                                                         cb, rpl, G));
         else
             SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, cb > 0 ? wgs : n_rt * n_tiles, s,
                       k_error_tiles_bf16<false><<<wgs, 256, sizeof(TileBf16Smem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym, n_slots,
-                                                                                        cb, rpl));
+                                                                                        cb, rpl, G));
         for (int b = 0; b < batch; ++b) SLK_RUN("error_gemm_f32", 0, 0, s, f32_layer(b, sym + b, 1));
     } else {
         for (int b = 0; b < batch; ++b)
             SLK_RUN("error_gemm", 2.0 * rpl * n * n, 8.0 * rpl * n + 4.0 * n * n + (G ? 4.0 * rpl * n : 0.0), s,
-                    f32_layer(b, try_sym ? sym + b : nullptr, 0));
+                    f32_layer(b, try_sym && G == nullptr ? sym + b : nullptr, 0));  // (its symmetric shortcut does not produce G)
     }
     SLK_RUN("error_reduce", 0, 4.0 * R * n_slots, s, k_error_reduce<<<(R + 255) / 256, 256, 0, s>>>(partial, R, n_slots, row_err));
     return SLK_OK;

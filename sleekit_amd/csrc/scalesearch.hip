@@ -7,6 +7,8 @@
 // order exactly (same tree as prepare.hip: k_diag_mean) so that ties and near-ties fall the same way.
 // One workgroup per row: the row stays in registers for the whole search, terms go through LDS,
 // leaf pieces are summed one per thread, the tree is folded level by level.
+#include <stdlib.h>
+
 #include "npsum.h"
 
 namespace slk {
@@ -86,6 +88,87 @@ __global__ __launch_bounds__(256) void k_scale_search(const float *__restrict__ 
     if (t == 0) out[r] = b * best_f;  // scaling.py:134
 }
 
+// The same search for rows whose NumPy summation tree is REGULAR: n = L * m with L = 2^k leaves of m <= 128
+// elements, m a multiple of 8 (4096 = 32 x 128, 3072 = 32 x 96, 1024 = 8 x 128, 768 = 8 x 96, ...).  NumPy's leaf is
+// eight running sums r[a] += x[8 i + a] combined as ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), and its tree a
+// perfect binary one over the leaves in order -- i.e. 8 L independent chains of m / 8 sequential adds, then an
+// xor-shuffle tree (offsets 1, 2, 4 inside a leaf, 8, 16, 32 over the leaves of a wave, LDS across waves): the same
+// additions in the same order with every thread busy and no term ever written to LDS.  A thread keeps its m / 8
+// elements of the row (and of the diagonal) in registers for the whole search.  When a row needs fewer than 256
+// chains, 256 / (8 L) factors are evaluated side by side; the first smallest error wins, as in the sequential scan.
+// (The general kernel above writes the terms to LDS and sums a leaf per thread: 4.5 ms for 100 factors at 4096 x 4096.)
+template <int S>  // S = m / 8 adds per chain
+__global__ __launch_bounds__(256) void k_scale_search_regular(const float *__restrict__ W, const float *__restrict__ base,
+                                                              const float *__restrict__ factors, int n_factors,
+                                                              const float *__restrict__ hdiag, int R, int n, Grid g,
+                                                              float *__restrict__ out, int L) {
+    __shared__ float wsum[2][4];
+    __shared__ float g_err[4];
+    __shared__ int g_idx[4];
+    const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int C = 8 * L, m = 8 * S;            // chains per factor (64, 128 or 256)
+    const int groups = 256 / C, waves_per_group = C / 64;
+    const int fg = t / C, chain = t % C;
+    const int leaf = chain >> 3, a = chain & 7;
+    const float *w = W + (size_t)r * n;
+    float wv[S], hv[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const int j = leaf * m + a + 8 * i;
+        wv[i] = w[j];
+        hv[i] = hdiag ? hdiag[j] : 1.0f;
+    }
+    const float b = base[r];
+    float best_err = __builtin_huge_valf();
+    int best_idx = 0x7fffffff;
+    const int rounds = (n_factors + groups - 1) / groups;
+    for (int it = 0; it < rounds; ++it) {
+        const int f = it * groups + fg;
+        const float fac = factors[min(f, n_factors - 1)];
+        const float sc = fac * b;     // scaling.py:128
+        const float inv = 1.0f / sc;  // scaling.py:80
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const float x = wv[i];
+            const float q = cb_value(x / sc, g) / inv;
+            const float e = q - x;
+            const float e2 = e * e;
+            const float term = hdiag ? hv[i] * e2 : e2;
+            v = (i == 0) ? term : v + term;
+        }
+#pragma unroll
+        for (int msk = 1; msk <= 32; msk <<= 1) v = v + __shfl_xor(v, msk, 64);  // leaf (1, 2, 4), then the wave's 8 leaves
+        float total = v;
+        if (waves_per_group > 1) {
+            if (lane == 0) wsum[it & 1][wave] = v;
+            __syncthreads();
+            total = waves_per_group == 2 ? wsum[it & 1][wave & ~1] + wsum[it & 1][wave | 1]
+                                         : (wsum[it & 1][0] + wsum[it & 1][1]) + (wsum[it & 1][2] + wsum[it & 1][3]);
+        }
+        if (f < n_factors && total < best_err) {  // strict: the first minimum is kept (scaling.py:131-133)
+            best_err = total;
+            best_idx = f;
+        }
+    }
+    // the groups scanned interleaved factor lists: smallest error, ties to the smaller index = the sequential scan's choice
+    if (chain == 0) {
+        g_err[fg] = best_err;
+        g_idx[fg] = best_idx;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float be = g_err[0];
+        int bi = g_idx[0];
+        for (int q = 1; q < groups; ++q)
+            if (g_err[q] < be || (g_err[q] == be && g_idx[q] < bi)) {
+                be = g_err[q];
+                bi = g_idx[q];
+            }
+        out[r] = bi < n_factors ? b * factors[bi] : b * __builtin_huge_valf();  // scaling.py:134
+    }
+}
+
 // best/err bookkeeping for the full-Hessian and OBQ searches, whose errors come from slk_row_errors
 __global__ __launch_bounds__(256) void k_search_update(const float *__restrict__ err, float factor, int R,
                                                        float *__restrict__ best_err, float *__restrict__ best_f) {
@@ -135,8 +218,37 @@ int slk_scale_search(const float *W, const float *base, const float *factors, in
     SLK_REQUIRE(W && base && factors && out && R > 0 && n > 0 && n_factors > 0, "bad arguments");
     SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
     hipStream_t s = as_stream(stream);
+    const Grid g = make_grid(levels, lo, hi, table);
+    // regular summation tree (see k_scale_search_regular): L = 2^k leaves of m = 8 S elements, 64 ... 256 chains
+    int m = n, L = 1;
+    bool regular = true;
+    while (m > 128 && regular) {
+        regular = m % 2 == 0 && (m / 2) % 8 == 0;
+        m /= 2;
+        L *= 2;
+    }
+    regular = regular && m % 8 == 0 && m >= 8 && (L == 8 || L == 16 || L == 32) && getenv("SLK_NO_REGULAR_SEARCH") == nullptr;
+    if (regular) {
+#define SLK_SEARCH_CASE(SV)                                                                                                     \
+    case SV:                                                                                                                    \
+        SLK_RUN("scale_search", 0, 4.0 * R * n, s,                                                                              \
+                k_scale_search_regular<SV><<<R, 256, 0, s>>>(W, base, factors, n_factors, hdiag, R, n, g, out, L));             \
+        return SLK_OK;
+        switch (m / 8) {
+            SLK_SEARCH_CASE(16)
+            SLK_SEARCH_CASE(15)
+            SLK_SEARCH_CASE(14)
+            SLK_SEARCH_CASE(13)
+            SLK_SEARCH_CASE(12)
+            SLK_SEARCH_CASE(11)
+            SLK_SEARCH_CASE(10)
+            SLK_SEARCH_CASE(9)
+            default: break;  // leaves of 64 elements or fewer: the general kernel
+        }
+#undef SLK_SEARCH_CASE
+    }
     SLK_RUN("scale_search", 0, 4.0 * R * n, s,
-            k_scale_search<1><<<R, 256, search_smem(n), s>>>(W, base, factors, n_factors, hdiag, R, n, make_grid(levels, lo, hi, table), out));
+            k_scale_search<1><<<R, 256, search_smem(n), s>>>(W, base, factors, n_factors, hdiag, R, n, g, out));
     return SLK_OK;
 }
 

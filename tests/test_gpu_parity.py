@@ -799,3 +799,20 @@ def test_graph_replay_of_a_layer(amd):
     torch.cuda.synchronize()
     with pytest.raises(np.linalg.LinAlgError):
         g.check()
+
+
+@pytest.mark.parametrize("n", [768, 1024, 1536, 2048, 3072, 4096])
+def test_scale_search_regular_tree(amd, monkeypatch, n):
+    """Row lengths whose NumPy summation tree is regular (2^k leaves of <= 128 elements) take the chain-per-thread
+    search kernel: same scales, bit for bit, as NumPy (the oracle) and as the general kernel."""
+    R = 12
+    g = grid.UniformGrid(4, -1, 1)
+    cb = amd.codebook.UniformCodebook(4, -1, 1)
+    W = synth.make_weights(R, n, 7000 + n)
+    hd = (np.abs(synth.normal_grid(7000 + n, 8, 1, n)[0]) * 3 + 0.1).astype(np.float32)
+    for H in (None, hd):
+        got = amd.scaling.compute_min_mse_scaling(W, cb, H=H, grid_size=37)
+        assert np.array_equal(got, scaling_ref.best_grid_scale(W, g, H=H, grid_size=37)), (n, H is None)
+        monkeypatch.setenv("SLK_NO_REGULAR_SEARCH", "1")
+        assert np.array_equal(got, amd.scaling.compute_min_mse_scaling(W, cb, H=H, grid_size=37))
+        monkeypatch.delenv("SLK_NO_REGULAR_SEARCH")

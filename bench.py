@@ -349,6 +349,7 @@ def main():
                 "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(t_setup, 1),
                 "peak_hbm_gb": round(peak_hbm / 2**30, 2),
                 "streams": {"factor": streams[0], "loop": streams[1]}, "hip_graphs": bool(args.graphs),
+                "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
             },
             "roofline": roofline, "cpu_baseline": cpu, "layer_error": err0, "hessian_accumulate": hess,
         }

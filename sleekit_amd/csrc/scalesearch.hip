@@ -97,11 +97,30 @@ __global__ __launch_bounds__(256) void k_scale_search(const float *__restrict__ 
 // elements of the row (and of the diagonal) in registers for the whole search.  When a row needs fewer than 256
 // chains, 256 / (8 L) factors are evaluated side by side; the first smallest error wins, as in the sequential scan.
 // (The general kernel above writes the terms to LDS and sums a leaf per thread: 4.5 ms for 100 factors at 4096 x 4096.)
+// a / b, correctly rounded, from y = RN(1 / b) by Markstein's sequence (q0 = RN(a y); r = a - b q0, exact in one fma;
+// q = RN(q0 + r y)): equal to the IEEE quotient when b's significand is not all ones and nothing over- or underflows
+// (`ok`, decided once per divisor; the magnitude test sends the rare tiny or huge dividend to the true divide).
+// Three dependent operations instead of the dozen of v_div_scale / v_div_fmas / v_div_fixup.
+__device__ __forceinline__ float div_by(float a, float b, float y, bool ok) {
+    const float mag = fabsf(a);
+    if (ok && mag > 1.0e-30f && mag < 1.0e30f) {
+        const float q0 = a * y;
+        const float r = __builtin_fmaf(-b, q0, a);
+        return __builtin_fmaf(r, y, q0);
+    }
+    return a / b;
+}
+__device__ __forceinline__ bool divisor_ok(float b) {
+    const unsigned bits = __float_as_uint(b);
+    const float mag = fabsf(b);
+    return (bits & 0x7FFFFFu) != 0x7FFFFFu && mag > 1.0e-30f && mag < 1.0e30f;
+}
+
 template <int S>  // S = m / 8 adds per chain
 __global__ __launch_bounds__(256) void k_scale_search_regular(const float *__restrict__ W, const float *__restrict__ base,
                                                               const float *__restrict__ factors, int n_factors,
                                                               const float *__restrict__ hdiag, int R, int n, Grid g,
-                                                              float *__restrict__ out, int L) {
+                                                              float *__restrict__ out, int L, int fast_div) {
     __shared__ float wsum[2][4];
     __shared__ float g_err[4];
     __shared__ int g_idx[4];
@@ -122,16 +141,30 @@ __global__ __launch_bounds__(256) void k_scale_search_regular(const float *__res
     float best_err = __builtin_huge_valf();
     int best_idx = 0x7fffffff;
     const int rounds = (n_factors + groups - 1) / groups;
+    const bool uniform = g.table == nullptr;
+    const float inv_step = 1.0f / g.step;
+    const bool ok_step = fast_div && uniform && divisor_ok(g.step) && divisor_ok(inv_step);
     for (int it = 0; it < rounds; ++it) {
         const int f = it * groups + fg;
         const float fac = factors[min(f, n_factors - 1)];
         const float sc = fac * b;     // scaling.py:128
         const float inv = 1.0f / sc;  // scaling.py:80
+        const float back = 1.0f / inv;  // RN(1 / inv): the reciprocal the second division is built from
+        const bool ok_sc = fast_div && divisor_ok(sc) && divisor_ok(inv), ok_inv = ok_sc && divisor_ok(back);
         float v = 0.0f;
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             const float x = wv[i];
-            const float q = cb_value(x / sc, g) / inv;
+            const float xs = div_by(x, sc, inv, ok_sc);  // x / sc
+            float cv;
+            if (ok_step) {  // codebook.py:47-54 with the division by the step replaced likewise
+                float tq = div_by(xs - g.zero, g.step, inv_step, true);
+                tq = fminf(fmaxf(rintf(tq), 0.0f), g.top);
+                cv = tq * g.step + g.zero;
+            } else {
+                cv = cb_value(xs, g);
+            }
+            const float q = div_by(cv, inv, back, ok_inv);  // cv / inv
             const float e = q - x;
             const float e2 = e * e;
             const float term = hdiag ? hv[i] * e2 : e2;
@@ -228,11 +261,12 @@ int slk_scale_search(const float *W, const float *base, const float *factors, in
         L *= 2;
     }
     regular = regular && m % 8 == 0 && m >= 8 && (L == 8 || L == 16 || L == 32) && getenv("SLK_NO_REGULAR_SEARCH") == nullptr;
+    const int fast_div = getenv("SLK_NO_FAST_SEARCH_DIV") == nullptr;
     if (regular) {
 #define SLK_SEARCH_CASE(SV)                                                                                                     \
     case SV:                                                                                                                    \
         SLK_RUN("scale_search", 0, 4.0 * R * n, s,                                                                              \
-                k_scale_search_regular<SV><<<R, 256, 0, s>>>(W, base, factors, n_factors, hdiag, R, n, g, out, L));             \
+                k_scale_search_regular<SV><<<R, 256, 0, s>>>(W, base, factors, n_factors, hdiag, R, n, g, out, L, fast_div));   \
         return SLK_OK;
         switch (m / 8) {
             SLK_SEARCH_CASE(16)

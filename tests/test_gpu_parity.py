@@ -816,3 +816,26 @@ def test_scale_search_regular_tree(amd, monkeypatch, n):
         monkeypatch.setenv("SLK_NO_REGULAR_SEARCH", "1")
         assert np.array_equal(got, amd.scaling.compute_min_mse_scaling(W, cb, H=H, grid_size=37))
         monkeypatch.delenv("SLK_NO_REGULAR_SEARCH")
+
+
+def test_scale_search_fast_division(amd, monkeypatch):
+    """The regular-tree search replaces its three float32 divisions per element by Markstein's fma sequence where
+    that is exact: same choices as with true divides and as NumPy, on rows with a wide dynamic range, zeros,
+    denormals, and divisors whose significand is all ones (sent to the true divide)."""
+    rng = np.random.default_rng(5)
+    R, n = 64, 1024
+    W = (rng.standard_normal((R, n)) * np.exp(rng.uniform(-12, 6, (R, 1)))).astype(np.float32)
+    W[0, :16] = [0.0, -0.0, 1e-45, -1e-45, 1e-39, 3e-38, 1e-30, -1e-31, 1e30, -3e37, 1.0, -1.0, 0.5, 2.0, 1e-20, 1e20]
+    W[1] *= np.float32(1e-25)
+    W[2] *= np.float32(1e18)
+    hd = (np.abs(rng.standard_normal(n)) + 0.01).astype(np.float32)
+    for levels, lo, hi in ((8, -1.0, 1.0), (4, -1.0, 1.0), (3, -1.0, 1.0), (16, -0.75, 1.25)):
+        g = grid.UniformGrid(levels, lo, hi)
+        cb = amd.codebook.UniformCodebook(levels, lo, hi)
+        for H in (None, hd):
+            got = amd.scaling.compute_min_mse_scaling(W, cb, H=H, grid_size=150)
+            monkeypatch.setenv("SLK_NO_FAST_SEARCH_DIV", "1")
+            slow = amd.scaling.compute_min_mse_scaling(W, cb, H=H, grid_size=150)
+            monkeypatch.delenv("SLK_NO_FAST_SEARCH_DIV")
+            assert np.array_equal(got, slow), (levels, H is None)
+            assert np.array_equal(got, scaling_ref.best_grid_scale(W, g, H=H, grid_size=150)), (levels, H is None)

@@ -53,6 +53,25 @@ __global__ __launch_bounds__(256) void k_row_norm_scale(const float *__restrict_
     if (threadIdx.x == 0) scale[blockIdx.x] = sqrtf(fmaxf(total / (float)n, 1.0e-16f));  // scaling.py:40-41
 }
 
+// a / b, correctly rounded, from y = RN(1 / b) by Markstein's sequence (q0 = RN(a y); r = a - b q0, exact in one fma;
+// q = RN(q0 + r y)): equal to the IEEE quotient when b's significand is not all ones and nothing over- or underflows
+// (`ok`, decided once per divisor; the magnitude test sends the rare tiny or huge dividend to the true divide).
+// Three dependent operations instead of the dozen of v_div_scale / v_div_fmas / v_div_fixup.
+__device__ __forceinline__ float div_by(float a, float b, float y, bool ok) {
+    const float mag = fabsf(a);
+    if (ok && mag > 1.0e-30f && mag < 1.0e30f) {
+        const float q0 = a * y;
+        const float r = __builtin_fmaf(-b, q0, a);
+        return __builtin_fmaf(r, y, q0);
+    }
+    return a / b;
+}
+__device__ __forceinline__ bool divisor_ok(float b) {
+    const unsigned bits = __float_as_uint(b);
+    const float mag = fabsf(b);
+    return (bits & 0x7FFFFFu) != 0x7FFFFFu && mag > 1.0e-30f && mag < 1.0e30f;
+}
+
 // ------------------------------------------------------------------ grid search
 // mode 0: error = sum E^2;  mode 1: error = sum hdiag_j * E_j^2   (scaling.py:84-95)
 // E = quantize_with_scaling(w, s * base) - w with round-to-nearest quantization (scaling.py:73, 79-80)
@@ -60,7 +79,7 @@ template <int EPT>
 __global__ __launch_bounds__(256) void k_scale_search(const float *__restrict__ W, const float *__restrict__ base,
                                                       const float *__restrict__ factors, int n_factors,
                                                       const float *__restrict__ hdiag, int R, int n, Grid g,
-                                                      float *__restrict__ out) {
+                                                      float *__restrict__ out, int fast_div) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SumTree *trees = reinterpret_cast<SumTree *>(smem_raw);
     float *terms = reinterpret_cast<float *>(smem_raw + 2 * sizeof(SumTree));
@@ -69,13 +88,26 @@ __global__ __launch_bounds__(256) void k_scale_search(const float *__restrict__ 
     prepare_trees(trees, n);
     const float b = base[r];
     float best_err = __builtin_huge_valf(), best_f = __builtin_huge_valf();
+    const float inv_step = 1.0f / g.step;
+    const bool ok_step = fast_div && g.table == nullptr && divisor_ok(g.step) && divisor_ok(inv_step);
     for (int f = 0; f < n_factors; ++f) {
         const float fac = factors[f];
         const float sc = fac * b;         // scaling.py:128
         const float inv = 1.0f / sc;      // scaling.py:80
+        const float back = 1.0f / inv;
+        const bool ok_sc = fast_div && divisor_ok(sc) && divisor_ok(inv), ok_inv = ok_sc && divisor_ok(back);
         const float err = row_sum_numpy(trees, terms, n, [&](int j) {
             const float x = w[j];
-            const float q = cb_value(x / sc, g) / inv;
+            const float xs = div_by(x, sc, inv, ok_sc);
+            float cv;
+            if (ok_step) {
+                float tq = div_by(xs - g.zero, g.step, inv_step, true);
+                tq = fminf(fmaxf(rintf(tq), 0.0f), g.top);
+                cv = tq * g.step + g.zero;
+            } else {
+                cv = cb_value(xs, g);
+            }
+            const float q = div_by(cv, inv, back, ok_inv);
             const float e = q - x;
             const float e2 = e * e;
             return hdiag ? hdiag[j] * e2 : e2;
@@ -97,25 +129,6 @@ __global__ __launch_bounds__(256) void k_scale_search(const float *__restrict__ 
 // elements of the row (and of the diagonal) in registers for the whole search.  When a row needs fewer than 256
 // chains, 256 / (8 L) factors are evaluated side by side; the first smallest error wins, as in the sequential scan.
 // (The general kernel above writes the terms to LDS and sums a leaf per thread: 4.5 ms for 100 factors at 4096 x 4096.)
-// a / b, correctly rounded, from y = RN(1 / b) by Markstein's sequence (q0 = RN(a y); r = a - b q0, exact in one fma;
-// q = RN(q0 + r y)): equal to the IEEE quotient when b's significand is not all ones and nothing over- or underflows
-// (`ok`, decided once per divisor; the magnitude test sends the rare tiny or huge dividend to the true divide).
-// Three dependent operations instead of the dozen of v_div_scale / v_div_fmas / v_div_fixup.
-__device__ __forceinline__ float div_by(float a, float b, float y, bool ok) {
-    const float mag = fabsf(a);
-    if (ok && mag > 1.0e-30f && mag < 1.0e30f) {
-        const float q0 = a * y;
-        const float r = __builtin_fmaf(-b, q0, a);
-        return __builtin_fmaf(r, y, q0);
-    }
-    return a / b;
-}
-__device__ __forceinline__ bool divisor_ok(float b) {
-    const unsigned bits = __float_as_uint(b);
-    const float mag = fabsf(b);
-    return (bits & 0x7FFFFFu) != 0x7FFFFFu && mag > 1.0e-30f && mag < 1.0e30f;
-}
-
 template <int S>  // S = m / 8 adds per chain
 __global__ __launch_bounds__(256) void k_scale_search_regular(const float *__restrict__ W, const float *__restrict__ base,
                                                               const float *__restrict__ factors, int n_factors,
@@ -282,7 +295,7 @@ int slk_scale_search(const float *W, const float *base, const float *factors, in
 #undef SLK_SEARCH_CASE
     }
     SLK_RUN("scale_search", 0, 4.0 * R * n, s,
-            k_scale_search<1><<<R, 256, search_smem(n), s>>>(W, base, factors, n_factors, hdiag, R, n, g, out));
+            k_scale_search<1><<<R, 256, search_smem(n), s>>>(W, base, factors, n_factors, hdiag, R, n, g, out, fast_div));
     return SLK_OK;
 }
 

@@ -11,7 +11,8 @@
  *     matrices are dense row-major; `R` = output rows of W, `n` = input columns;
  *   - `stream` is a hipStream_t passed as void*; calls only enqueue work and never
  *     synchronise, allocate or copy from host memory, so they can be captured
- *     into a hipGraph;
+ *     into a hipGraph (sleekit_amd/graphs.py does; zero-fills and copies inside the library are kernels, not
+ *     hipMemsetAsync / hipMemcpyAsync, whose graph nodes did not replay faithfully on ROCm 7.2);
  *   - scratch comes from a caller-provided workspace of at least
  *     slk_workspace_bytes(R, n) bytes, 256-byte aligned; one workspace may be
  *     shared by consecutive calls on the same stream;
@@ -57,7 +58,9 @@ extern "C" {
 
 typedef void *slk_stream_t;
 
-/* Library / device --------------------------------------------------------- */
+/* Library / device ---------------------------------------------------------
+ * slk_abi_version: 3.  History: 2 = every quantizing entry takes (levels, lo, hi, table); 3 adds the batch forms
+ * (slk_gptq_quantize_batch, slk_row_errors_batch, slk_workspace_bytes_batch) and slk_symmetry_flag.            */
 int slk_abi_version(void);
 const char *slk_last_error(void);
 /* Scratch bytes that any call below may use for an (R, n) layer. */

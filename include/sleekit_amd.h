@@ -143,6 +143,10 @@ int slk_factor_pack(const double *U, const long long *order, const int *info, in
                     slk_stream_t stream);
 int slk_factor_unpack(const void *payload, int n, double *U, long long *order, int *info,
                       slk_stream_t stream);
+/*     ... writing the diagonal and above only: for a U buffer whose lower triangle is zero already (zeroed once,
+ *     reused round after round: a third less traffic than rewriting the zeros).                          */
+int slk_factor_unpack_upper(const void *payload, int n, double *U, long long *order, int *info,
+                            slk_stream_t stream);
 
 /* a5+a8+a9+a10  quantize_opt without local search  (sleekit/obq.py:106-137, 202-213)
  *     W: R x n float32.  scale: per-row divisor applied on load (NULL: W is used as is).

@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void k_pack_factor(const double *__restrict__ 
     }
 }
 
+template <bool UPPER_ONLY>
 __global__ __launch_bounds__(256) void k_unpack_factor(const long long *__restrict__ payload, int n, double *__restrict__ U,
                                                        long long *__restrict__ order, int *__restrict__ info) {
     if (blockIdx.x == 0) {
@@ -175,7 +176,11 @@ __global__ __launch_bounds__(256) void k_unpack_factor(const long long *__restri
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         double *dst = U + (size_t)i * n;
         const double *src = tri + tri_offset(i, n) - i;
-        for (int j = threadIdx.x; j < n; j += blockDim.x) dst[j] = (j >= i) ? src[j] : 0.0;
+        if (UPPER_ONLY) {  // the part below the diagonal is known to be zero already (a buffer zeroed once and reused)
+            for (int j = i + threadIdx.x; j < n; j += blockDim.x) dst[j] = src[j];
+        } else {
+            for (int j = threadIdx.x; j < n; j += blockDim.x) dst[j] = (j >= i) ? src[j] : 0.0;
+        }
     }
 }
 
@@ -319,7 +324,15 @@ int slk_factor_unpack(const void *payload, int n, double *U, long long *order, i
     SLK_REQUIRE(U && order && info && payload && n > 0, "bad arguments");
     hipStream_t s = as_stream(stream);
     SLK_RUN("factor_unpack", 0, 4.0 * n * (n + 1.0) + 8.0 * n * n, s,
-            k_unpack_factor<<<n < 2048 ? n : 2048, 256, 0, s>>>(static_cast<const long long *>(payload), n, U, order, info));
+            k_unpack_factor<false><<<n < 2048 ? n : 2048, 256, 0, s>>>(static_cast<const long long *>(payload), n, U, order, info));
+    return SLK_OK;
+}
+
+int slk_factor_unpack_upper(const void *payload, int n, double *U, long long *order, int *info, slk_stream_t stream) {
+    SLK_REQUIRE(U && order && info && payload && n > 0, "bad arguments");
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("factor_unpack", 0, 4.0 * n * (n + 1.0) + 4.0 * n * (n + 1.0), s,
+            k_unpack_factor<true><<<n < 2048 ? n : 2048, 256, 0, s>>>(static_cast<const long long *>(payload), n, U, order, info));
     return SLK_OK;
 }
 

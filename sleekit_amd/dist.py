@@ -148,12 +148,19 @@ class HipBackend:
         eng = self.engine
         B, n = len(round_layers), round_layers[0]["H"].shape[0]
         device = round_layers[0]["W"].device
-        U = torch.empty((B, n, n), dtype=torch.float64, device=device)
+        # the stacked factors live in a buffer per stream, zeroed once: only the upper triangles are rewritten each round
+        # (use on one stream is ordered; rounds on other streams have buffers of their own)
+        if not hasattr(self, "_ustacks"):
+            self._ustacks = {}
+        key = (device.index, dev.stream_handle(), B, n)
+        U = self._ustacks.get(key)
+        if U is None:
+            U = self._ustacks[key] = torch.zeros((B, n, n), dtype=torch.float64, device=device)
         order = torch.empty((B, n), dtype=torch.int64, device=device)
         info = torch.empty(B, dtype=torch.int32, device=device)
         for b, payload in enumerate(payloads):
-            _lib.check(_lib.lib.slk_factor_unpack(dev.ptr(payload), n, U[b].data_ptr(), order[b].data_ptr(),
-                                                  info[b:b + 1].data_ptr(), dev.stream_handle()))
+            _lib.check(_lib.lib.slk_factor_unpack_upper(dev.ptr(payload), n, U[b].data_ptr(), order[b].data_ptr(),
+                                                        info[b:b + 1].data_ptr(), dev.stream_handle()))
         W = torch.stack([lay["W"][lo:hi] for lay in round_layers])
         sc = torch.stack([lay["scale"][lo:hi] for lay in round_layers]) if round_layers[0].get("scale") is not None else None
         cb = eng.require_uniform(self.quantizer)

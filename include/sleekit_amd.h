@@ -59,10 +59,18 @@ extern "C" {
 typedef void *slk_stream_t;
 
 /* Library / device ---------------------------------------------------------
- * slk_abi_version: 3.  History: 2 = every quantizing entry takes (levels, lo, hi, table); 3 adds the batch forms
- * (slk_gptq_quantize_batch, slk_row_errors_batch, slk_workspace_bytes_batch) and slk_symmetry_flag.            */
+ * slk_abi_version: 4.  History: 2 = every quantizing entry takes (levels, lo, hi, table); 3 adds the batch forms
+ * (slk_gptq_quantize_batch, slk_row_errors_batch, slk_workspace_bytes_batch) and slk_symmetry_flag; 4 adds the
+ * `trace` argument of slk_local_search and slk_set_option / slk_get_option.                                    */
 int slk_abi_version(void);
 const char *slk_last_error(void);
+/* Run-time switches between code paths that give the same results (the tests hold them to that) or that shape a
+ * measurement: "no_window2", "no_fast_leaf", "no_defer", "win_dbg", "no_regular_search", "no_fast_search_div",
+ * "no_error_splitk", "error_cb", "no_sym_error", "no_bf16_error", "no_bf16_dma", "no_bf16_hessian" (case-insensitive,
+ * an "SLK_" prefix is accepted).  Initial values are read ONCE from the environment (SLK_NO_WINDOW2=1 ...);
+ * afterwards only these calls change them.  Process-wide, thread-safe; no reference counterpart.              */
+int slk_set_option(const char *name, int value);
+int slk_get_option(const char *name);
 /* Scratch bytes that any call below may use for an (R, n) layer. */
 size_t slk_workspace_bytes(int R, int n);
 
@@ -194,10 +202,14 @@ int slk_symmetry_flag(const float *H, int n, int *flag, slk_stream_t stream);
 /* a12+a13 quantize_local_search  (sleekit/obq.py:220-358)
  *     W, Q: R x n float32 in the scaled domain; Q is updated in place, idx
  *     (may be NULL) receives the indices of the result.  `moves` best-first
- *     single-weight moves per row.                                             */
+ *     single-weight moves per row.  The interaction sum of every move (obq.py:328) is taken in NumPy's
+ *     pairwise order, so that from equal initial gains the moves are the reference's bit for bit.
+ *     trace (may be NULL): R x moves int32, the moves taken -- 2 * column + (1: up, 0: down), or -1 from
+ *     the first move on at which the row had nothing left to gain (parity tests compare it with the
+ *     reference's sequence of moves to find where, if anywhere, a near-tie fell the other way).      */
 int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
-                     double hi, const float *table, int moves, uint8_t *idx, void *workspace, size_t ws_bytes,
-                     slk_stream_t stream);
+                     double hi, const float *table, int moves, uint8_t *idx, int *trace, void *workspace,
+                     size_t ws_bytes, slk_stream_t stream);
 
 /* Scale selection: the callers' pre-step -------------------------- */
 /* compute_non_saturating_scaling (sleekit/scaling.py:44-55): scale[r] = max(max_r / hi_code,

@@ -15,6 +15,7 @@ Restates the hot path of the reference `sleekit/obq.py`:
     quantize_layer        obq.py:169-217  (quantize_opt)
     flip_gains            obq.py:220-231  (compute_gain)
     local_search          obq.py:234-358  (LocalSearchQuantizer + quantize_local_search)
+    move_record           (no counterpart) how close each local-search decision was: parity evidence
 
 The reference recurses over views; here the recursion is flattened once into
 an explicit list of operations on absolute column ranges.  Every operation
@@ -301,11 +302,98 @@ class _SearchState:
         self._apply(-1, go_down)
 
 
-def local_search(W, Q, H, grid, moves):
-    """obq.py:349-358: returns the input object itself when moves == 0."""
+def local_search(W, Q, H, grid, moves, records=None):
+    """obq.py:349-358: returns the input object itself when moves == 0.
+
+    records (a list, optional): receives one `move_record` per move -- how close every row's decision was
+    (see near_tie_summary); parity tests use it to tell a near-tie that fell the other way from a wrong move."""
     if moves == 0:
         return Q
     state = _SearchState(W, Q, H, grid)
+    noise = gain_noise_scale(W, Q, H) if records is not None else None
     for _ in range(moves):
+        if records is not None:
+            records.append(move_record(state.gain[+1], state.gain[-1], state.cand[+1] - state.Q, state.cand[-1] - state.Q, noise))
         state.move()
     return state.Q
+
+
+# --------------------------------------------------------------------------
+# How close a move was: evidence for local-search parity (not part of the reference)
+# --------------------------------------------------------------------------
+def gain_noise_scale(W, Q0, H):
+    """A[r, j] = sum_k |W - Q0|[r, k] |H|[k, j]: the magnitude that bounds the rounding error of the initial
+    `delta @ H` (obq.py:231) -- two float32 dot products of length n over the same terms, summed in different
+    orders, differ by at most about 2 n 2^-24 A.  Every later gain update is computed from identical inputs by
+    identical arithmetic on both sides, so this initial difference is what separates two implementations."""
+    return np.abs(W - Q0).astype(np.float32) @ np.abs(H).astype(np.float32)
+
+
+def move_record(gain_up, gain_down, D_up, D_down, noise):
+    """Per row, for the move about to be taken (obq.py:338-346): the choice, the runner-up and their distance.
+
+    choice / runner : 2 * column + (1 = up, 0 = down), or -1 for "stay"
+    ratio           : (value of the choice - value of the runner-up) / (2^-24 * (noise of both)), where the
+                      noise of a candidate is 2 |step| A[r, column] (0 for a plain "stay"): the margin in units
+                      of one float32 rounding of the terms that make up the two gains.  A ratio below ~n means
+                      the decision is within the rounding error of the initial GEMM -- a near-tie.
+    "Stay" covers the reference's "no gain is positive" AND its moves onto the value a weight already has
+    (the top level's up-candidate is the top level; a rounding residue can make such a candidate's gain positive):
+    such a move changes neither Q nor any gain (every update term of obq.py:322-334 is multiplied by a zero
+    difference), so the row is in the same state at the next move and takes the same non-move again.
+    The alternatives are every real up move, every real down move and "stay" (value: the largest residue of
+    the non-moves, at least 0); the runner-up is the best of the others.
+    """
+    R, n = gain_up.shape
+    rows = np.arange(R)
+    both = np.concatenate([gain_down, gain_up], axis=1).astype(np.float64)  # code of entry e: 2 * (e % n) + (e // n)
+    real = np.concatenate([D_down, D_up], axis=1) != 0
+    cu, cd = gain_up.max(axis=1), gain_down.max(axis=1)
+    ju, jd = gain_up.argmax(axis=1), gain_down.argmax(axis=1)
+    go_up = (cu > cd) & (cu > 0)
+    go_down = ~go_up & (cd > 0)
+    entry = np.where(go_up, n + ju, jd)                       # the reference's pick among the 2 n entries
+    moves = (go_up | go_down) & real[rows, entry]
+    # "stay": its value is the best residue among the non-moves (or 0), its noise that candidate's
+    idle = np.where(real, -np.inf, both)
+    idle_entry = idle.argmax(axis=1)
+    idle_value = np.maximum(idle[rows, idle_entry], 0.0)
+    idle_code = np.where(idle[rows, idle_entry] > 0, 2 * (idle_entry % n) + idle_entry // n, -1)
+    # best real move other than the chosen one
+    others = np.where(real, both, -np.inf)
+    others[rows[moves], entry[moves]] = -np.inf
+    other_entry = others.argmax(axis=1)
+    other_value = others[rows, other_entry]
+    other_code = 2 * (other_entry % n) + other_entry // n
+
+    choice = np.where(moves, 2 * (entry % n) + entry // n, -1)
+    value = np.where(moves, both[rows, entry], idle_value)
+    stay_is_runner = moves & (idle_value >= other_value)
+    runner = np.where(stay_is_runner, -1, other_code)
+    runner_value = np.where(stay_is_runner, idle_value, other_value)
+
+    def cand_noise(code):
+        # the larger of the column's two steps: a gain carried across a move INTO the end of the codebook keeps the
+        # rounding residue of the step it was built with although its own step is then 0
+        col = np.maximum(code, 0) // 2
+        d = np.maximum(np.abs(D_up[rows, col]), np.abs(D_down[rows, col]))
+        return np.where(code >= 0, 2.0 * d.astype(np.float64) * noise[rows, col], 0.0)
+
+    stay_noise = cand_noise(idle_code)
+    scale = np.where(moves, cand_noise(choice), stay_noise) + np.where(stay_is_runner, stay_noise, cand_noise(other_code))
+    scale = scale * 2.0 ** -24
+    margin = value - runner_value
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.where(scale > 0, margin / scale, np.where(margin > 0, np.inf, 0.0))
+    ratio = np.where(np.isneginf(runner_value), np.inf, ratio)  # nothing else to do at all
+    return dict(choice=choice.astype(np.int32), runner=runner.astype(np.int32), ratio=ratio.astype(np.float32))
+
+
+def near_tie_summary(records, limit):
+    """Rows whose decision came within `limit` (a ratio, see move_record) at some move, with their full records:
+    dict(rows int32[K], choice int32[K, moves], runner int32[K, moves], ratio float32[K, moves])."""
+    choice = np.stack([r["choice"] for r in records], axis=1)
+    runner = np.stack([r["runner"] for r in records], axis=1)
+    ratio = np.stack([r["ratio"] for r in records], axis=1)
+    rows = np.flatnonzero((ratio < limit).any(axis=1)).astype(np.int32)
+    return dict(rows=rows, choice=choice[rows], runner=runner[rows], ratio=ratio[rows])

@@ -31,6 +31,8 @@ P = c_void_p  # device pointers travel as plain addresses
 PROTOTYPES = {
     "slk_abi_version": (c_int, []),
     "slk_last_error": (c_char_p, []),
+    "slk_set_option": (c_int, [c_char_p, c_int]),
+    "slk_get_option": (c_int, [c_char_p]),
     "slk_workspace_bytes": (c_size_t, [c_int, c_int]),
     "slk_codebook_apply": (c_int, [P, c_size_t, c_int, c_double, c_double, P, c_int, P, P]),
     "slk_rows_divide": (c_int, [P, P, c_int, c_int, c_int, P, P]),
@@ -60,7 +62,7 @@ PROTOTYPES = {
     "slk_row_errors": (c_int, [P, P, P, c_int, c_int, P, P, P, c_size_t, P]),
     "slk_row_errors_batch": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, c_size_t, P]),
     "slk_symmetry_flag": (c_int, [P, c_int, P, P]),
-    "slk_local_search": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P, c_size_t, P]),
+    "slk_local_search": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P, P, c_size_t, P]),
     "slk_scale_minmax": (c_int, [P, c_int, c_int, c_double, c_double, P, P]),
     "slk_scale_norm": (c_int, [P, c_int, c_int, P, P]),
     "slk_scale_search": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_double, c_double, P, P, P]),
@@ -92,6 +94,27 @@ for _name, (_res, _args) in PROTOTYPES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of step
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+def set_option(name, value):
+    """slk_set_option: run-time switch between equivalent code paths (see include/sleekit_amd.h)."""
+    check(lib.slk_set_option(name.encode(), int(value)))
+
+
+class option:
+    """`with option("no_window2", 1): ...` -- set for the block, restored afterwards."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = lib.slk_get_option(self.name.encode())
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 class SleekitAmdError(RuntimeError):

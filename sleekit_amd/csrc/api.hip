@@ -166,11 +166,78 @@ int slk_probe_mfma_f32(float *sink, int blocks, int iters, slk_stream_t stream) 
 
 }  // extern "C"
 
-// ------------------------------------------------------------------ per-launch profiler
+// ------------------------------------------------------------------ options, LDS opt-in
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
 #include <vector>
+#include <strings.h>
+
+namespace slk {
+namespace {
+const char *const kOptNames[OPT_COUNT] = {
+    "NO_FAST_LEAF", "NO_DEFER", "NO_WINDOW2", "WIN_DBG", "NO_REGULAR_SEARCH", "NO_FAST_SEARCH_DIV",
+    "NO_ERROR_SPLITK", "ERROR_CB", "NO_SYM_ERROR", "NO_BF16_ERROR", "NO_BF16_DMA", "NO_BF16_HESSIAN",
+};
+std::atomic<int> g_opts[OPT_COUNT];
+std::once_flag g_opts_once;
+void opts_from_env() {
+    for (int i = 0; i < OPT_COUNT; ++i) {
+        const std::string name = std::string("SLK_") + kOptNames[i];
+        const char *v = getenv(name.c_str());
+        int val = 0;
+        if (v) {
+            val = atoi(v);
+            if (val == 0 && v[0] != '0') val = 1;  // set without a number: on
+        }
+        g_opts[i].store(val, std::memory_order_relaxed);
+    }
+}
+int opt_index(const char *name) {
+    if (!name) return -1;
+    if (strncasecmp(name, "SLK_", 4) == 0) name += 4;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (strcasecmp(name, kOptNames[i]) == 0) return i;
+    return -1;
+}
+std::mutex g_lds_mu;
+std::map<std::pair<const void *, int>, size_t> g_lds_set;
+}  // namespace
+
+int opt(Opt o) {
+    std::call_once(g_opts_once, opts_from_env);
+    return g_opts[o].load(std::memory_order_relaxed);
+}
+
+hipError_t lds_opt_in(const void *kernel, size_t bytes) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_lds_mu);
+    size_t &have = g_lds_set[{kernel, device}];
+    if (have >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
+}  // namespace slk
+
+extern "C" {
+int slk_set_option(const char *name, int value) {
+    const int i = opt_index(name);
+    SLK_REQUIRE(i >= 0, "unknown option %s", name ? name : "(null)");
+    (void)opt((Opt)i);  // environment first, so that it cannot overwrite this later
+    g_opts[i].store(value, std::memory_order_relaxed);
+    return SLK_OK;
+}
+int slk_get_option(const char *name) {
+    const int i = opt_index(name);
+    return i < 0 ? 0 : opt((Opt)i);
+}
+}
+
+// ------------------------------------------------------------------ per-launch profiler
 
 namespace slk {
 namespace {

@@ -63,6 +63,30 @@ void prof_next_width(long workgroups);
         SLK_RUN(name, flops, bytes, stream, __VA_ARGS__); \
     } while (0)
 
+// Run-time switches (slk_set_option / slk_get_option; initial values read ONCE from the environment, SLK_<NAME>).
+// They select between code paths that give the same results (tests hold them to that) or shape measurements.
+enum Opt {
+    OPT_NO_FAST_LEAF,          // leaves: true divides instead of the exact-division fma sequence
+    OPT_NO_DEFER,              // window kernel: no deferred helper updates
+    OPT_NO_WINDOW2,            // general window kernel for every window
+    OPT_WIN_DBG,               // window kernels: measurement bits (8: cycle counters of workgroup 0, 16: U blocks from global)
+    OPT_NO_REGULAR_SEARCH,     // scale search: staged row sums for every row length
+    OPT_NO_FAST_SEARCH_DIV,    // scale search: true divides
+    OPT_NO_ERROR_SPLITK,       // layer error: never cut K into chunks
+    OPT_ERROR_CB,              // layer error: force this K-chunk count
+    OPT_NO_SYM_ERROR,          // layer error: ignore the symmetry of H
+    OPT_NO_BF16_ERROR,         // layer error: float32 MFMA kernel
+    OPT_NO_BF16_DMA,           // bfloat16 x 3 GEMMs: stage operands through registers
+    OPT_NO_BF16_HESSIAN,       // Hessian accumulation: float32 MFMA kernel
+    OPT_COUNT
+};
+int opt(Opt o);
+
+// Opt a kernel in to `bytes` of dynamic LDS (above the 64 KB default) on the CURRENT device; remembered per
+// (kernel, device), safe to call from several threads.  Returns a hipError_t.
+hipError_t lds_opt_in(const void *kernel, size_t bytes);
+#define SLK_LDS_OPT_IN(kernel, bytes) SLK_HIP(slk::lds_opt_in(reinterpret_cast<const void *>(kernel), (bytes)))
+
 static inline hipStream_t as_stream(slk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

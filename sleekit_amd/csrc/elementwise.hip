@@ -148,7 +148,7 @@ using namespace slk;
 
 extern "C" {
 
-int slk_abi_version(void) { return 3; }
+int slk_abi_version(void) { return 4; }
 
 const char *slk_last_error(void) { return g_error; }
 

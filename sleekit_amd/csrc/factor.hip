@@ -323,12 +323,7 @@ extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, vo
         return SLK_E_WS;
     }
     hipStream_t s = as_stream(stream);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_panel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelSmem)));
-        attr_set = true;
-    }
+    SLK_LDS_OPT_IN(k_chol_panel, sizeof(PanelSmem));
     SLK_RUN_W("clear_info", 0, 4, 1, s, k_clear_info<<<1, 1, 0, s>>>(info));
 
     for (int K0 = 0; K0 < ld; K0 += OUTER) {

@@ -873,27 +873,19 @@ extern "C" int slk_gptq_quantize_batch(const float *W, const float *scale, const
     unsigned step_bits;
     memcpy(&step_bits, &g.step, 4);
     const int fast_ok = table == nullptr && (step_bits & 0x7FFFFFu) != 0x7FFFFFu && g.step > 9.0e-13f && g.step < 1.0e12f &&
-                        getenv("SLK_NO_FAST_LEAF") == nullptr;
-    const int dbg = getenv("SLK_WIN_DBG") ? atoi(getenv("SLK_WIN_DBG")) : 0;
-    const bool no_defer = getenv("SLK_NO_DEFER") != nullptr;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gptq_window<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WindowSmem)));
-        SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gptq_window2),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Window2Smem)));
-        attr_set = true;
-    }
-    const bool periods_ok = n % 2 == 0 && (uintptr_t)U % 16 == 0 && getenv("SLK_NO_WINDOW2") == nullptr && (dbg & ~24) == 0;
+                        !opt(OPT_NO_FAST_LEAF);
+    const int dbg = opt(OPT_WIN_DBG);
+    const bool no_defer = opt(OPT_NO_DEFER) != 0;
+    SLK_LDS_OPT_IN(k_gptq_window<true>, sizeof(WindowSmem));
+    SLK_LDS_OPT_IN(k_gptq_window2, sizeof(Window2Smem));
+    const bool periods_ok = n % 2 == 0 && (uintptr_t)U % 16 == 0 && !opt(OPT_NO_WINDOW2) && (dbg & ~24) == 0;
 
     // rows staged through LDS when they fit and 16-byte accesses line up
     const bool perm_lds = order && n % 4 == 0 && n <= PERM_MAX && ((uintptr_t)W | (uintptr_t)Q | (uintptr_t)workspace) % 16 == 0 &&
                           (idx == nullptr || (uintptr_t)idx % 4 == 0);
-    static bool perm_attr = false;
-    if (perm_lds && !perm_attr) {
-        SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permute_in_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PERM_MAX * 4));
-        SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permute_out_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PERM_MAX * 4));
-        perm_attr = true;
+    if (perm_lds) {
+        SLK_LDS_OPT_IN(k_permute_in_lds, PERM_MAX * 4);
+        SLK_LDS_OPT_IN(k_permute_out_lds, PERM_MAX * 4);
     }
     if (perm_lds)
         SLK_RUN("permute_in", 0, 8.0 * R * n, s, k_permute_in_lds<<<R < 2048 ? R : 2048, 256, (size_t)n * 4, s>>>(W, scale, order, R, n, Qp, inv_order, rpl));

@@ -110,4 +110,102 @@ __device__ __forceinline__ void prepare_trees(SumTree *trees, int n) {
     __syncthreads();
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The same order for a 256-thread workgroup that sums one row per call, many times (the local search:
+// one interaction sum per move).  The tree of a chunk is held in HEAP numbering -- node h has children
+// 2h and 2h + 1 -- so every thread derives its node's range by walking the bits of h from the root: no
+// serial construction.  A chunk of <= 8192 elements is at most 7 levels deep (a right child is at most
+// len / 2 + 7.5 long: <= 8192 / 128 + 15 = 79 at depth 7), i.e. 256 heap slots per chunk; rows of up to
+// two chunks (n <= 16384).  Leaves are summed by 8 threads each -- NumPy's 8 interleaved accumulators --
+// and combined by xor-shuffles in NumPy's order ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); one wave then walks
+// the levels bottom-up.
+struct HeapSum {
+    short lo[512], len[512];  // slot = 256 * chunk + heap index (1..255); len 0: no such node
+    short leaf[512];          // the slots that are leaves, in no particular order
+    int n_leaves;
+    float val[512];
+};
+
+__device__ __forceinline__ void heap_sum_plan(HeapSum &p, int n) {  // all 256 threads; ends with a barrier
+    const int t = threadIdx.x;
+    if (t == 0) p.n_leaves = 0;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int lo = c * NP_CHUNK, len = min(NP_CHUNK, n - c * NP_CHUNK);
+        bool ok = t >= 1 && len > 0;
+        if (ok) {
+            const int depth = 31 - __clz(t);
+            for (int b = depth - 1; b >= 0; --b) {
+                if (len <= NP_BLOCK) {  // an ancestor is a leaf already
+                    ok = false;
+                    break;
+                }
+                const int h = (len / 2) & ~7;
+                if ((t >> b) & 1) {
+                    lo += h;
+                    len -= h;
+                } else {
+                    len = h;
+                }
+            }
+        }
+        p.lo[256 * c + t] = (short)lo;
+        p.len[256 * c + t] = ok ? (short)len : (short)0;
+        if (ok && len <= NP_BLOCK) p.leaf[atomicAdd(&p.n_leaves, 1)] = (short)(256 * c + t);
+    }
+    __syncthreads();
+}
+
+// position of element j in the staged row: a gap of 8 floats after every 128 keeps the 8 x 8 lanes of a wave
+// (8 leaves, 8 accumulators each) on distinct LDS banks when the leaves are 128 apart
+__device__ __forceinline__ int heap_sum_pos(int j) { return j + ((j >> 7) << 3); }
+__device__ __forceinline__ int heap_sum_floats(int n) { return heap_sum_pos(n) + 8; }
+
+// Sum of the n terms staged at terms[heap_sum_pos(j)] (written before the call; the call starts with a barrier).
+// Every thread returns the total.
+__device__ __forceinline__ float heap_sum(HeapSum &p, const float *terms, int n) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    for (int u = t; u < 8 * p.n_leaves; u += 256) {
+        const int slot = p.leaf[u >> 3], r = u & 7;
+        const int lo = p.lo[slot], len = p.len[slot];
+        float acc;
+        if (len < 8) {
+            acc = -0.0f;
+            if (r == 0)
+                for (int i = 0; i < len; ++i) acc = acc + terms[heap_sum_pos(lo + i)];
+        } else {
+            const int body = len - (len & 7);
+            acc = terms[heap_sum_pos(lo + r)];
+            for (int i = 8; i < body; i += 8) acc = acc + terms[heap_sum_pos(lo + i + r)];
+            acc = acc + __shfl_xor(acc, 1, 64);
+            acc = acc + __shfl_xor(acc, 2, 64);
+            acc = acc + __shfl_xor(acc, 4, 64);
+            if (r == 0)
+                for (int i = body; i < len; ++i) acc = acc + terms[heap_sum_pos(lo + i)];
+        }
+        if (r == 0) p.val[slot] = acc;
+    }
+    __syncthreads();
+    if (t < 64) {
+        for (int d = 6; d >= 0; --d) {
+            for (int k = t; k < (2 << d); k += 64) {
+                const int base = 256 * (k >> d), h = (1 << d) + (k & ((1 << d) - 1));
+                if (p.len[base + h] > NP_BLOCK) p.val[base + h] = p.val[base + 2 * h] + p.val[base + 2 * h + 1];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // one wave, LDS in order: only the compiler must not reorder
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (t == 0) {
+            float total = 0.0f + p.val[1];
+            if (n > NP_CHUNK) total = total + p.val[257];
+            p.val[0] = total;
+        }
+    }
+    __syncthreads();
+    return p.val[0];
+}
+
 }  // namespace slk

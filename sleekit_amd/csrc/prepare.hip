@@ -422,11 +422,7 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
     }
     SLK_RUN("rank_scatter", 0, 12.0 * n, s, k_rank_scatter<<<(n + 255) / 256, 256, 0, s>>>(rank, n, identity, order_out));
     if (n % 4 == 0 && n <= 16384 && (uintptr_t)H % 16 == 0) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather_reversed_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
-            attr_set = true;
-        }
+        SLK_LDS_OPT_IN(k_gather_reversed_lds, 16384 * 4);
         SLK_RUN("gather_reversed", 0, 4.0 * n * n + 4.0 * ld * ld, s,
                 k_gather_reversed_lds<<<ld < 2048 ? ld : 2048, 256, (size_t)n * 4, s>>>(H, n, ld, order_out, scal, A));
     } else {

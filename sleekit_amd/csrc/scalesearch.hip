@@ -273,8 +273,8 @@ int slk_scale_search(const float *W, const float *base, const float *factors, in
         m /= 2;
         L *= 2;
     }
-    regular = regular && m % 8 == 0 && m >= 8 && (L == 8 || L == 16 || L == 32) && getenv("SLK_NO_REGULAR_SEARCH") == nullptr;
-    const int fast_div = getenv("SLK_NO_FAST_SEARCH_DIV") == nullptr;
+    regular = regular && m % 8 == 0 && m >= 8 && (L == 8 || L == 16 || L == 32) && !opt(OPT_NO_REGULAR_SEARCH);
+    const int fast_div = !opt(OPT_NO_FAST_SEARCH_DIV);
     if (regular) {
 #define SLK_SEARCH_CASE(SV)                                                                                                     \
     case SV:                                                                                                                    \

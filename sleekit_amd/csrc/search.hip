@@ -13,6 +13,7 @@
 //
 // Initial gains (obq.py:231) reuse G = (W - Q) @ H from the error GEMM: delta @ H = -G exactly.
 #include "common.h"
+#include "npsum.h"
 
 namespace slk {
 
@@ -22,6 +23,7 @@ __device__ __forceinline__ float cand_down(float q, const Grid g) { return cb_do
 struct Best {
     float v;
     int j;
+    float q;  // the row's current value at column j (saves a broadcast once the move is chosen)
 };
 __device__ __forceinline__ Best better(Best a, Best b) {
     // larger value wins; on a tie the smaller column (first occurrence)
@@ -34,6 +36,7 @@ __device__ __forceinline__ Best wave_best(Best x) {
         Best o;
         o.v = __shfl_xor(x.v, m, 64);
         o.j = __shfl_xor(x.j, m, 64);
+        o.q = __shfl_xor(x.q, m, 64);
         x = better(x, o);
     }
     return x;
@@ -44,17 +47,22 @@ __global__ void k_extract_diag(const float *__restrict__ H, int n, float *__rest
     if (i < n) d[i] = H[(size_t)i * n + i];
 }
 
+// trace (may be NULL): moves ints per row, 2 * column + (1 = up, 0 = down) of every move taken, -1 from the
+// first move on at which the row had nothing left to gain (or only a "move" onto the value it already has).
 template <int EPT>
 __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ W, float *__restrict__ Q,
                                                       const float *__restrict__ H, const float *__restrict__ G,
                                                       const float *__restrict__ hdiag, int R, int n, Grid g,
-                                                      int moves, uint8_t *__restrict__ idx) {
+                                                      int moves, uint8_t *__restrict__ idx, int *__restrict__ trace) {
     __shared__ Best red_up[4], red_dn[4];
-    __shared__ float red_s[4];
+    __shared__ HeapSum plan;
+    extern __shared__ float terms[];  // heap_sum_floats(n): the products of the interaction sum, staged for NumPy's order
     const int row = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const size_t base = (size_t)row * n;
     const float NEG = -__builtin_huge_valf();
+
+    heap_sum_plan(plan, n);
 
     float w[EPT], q[EPT], gu[EPT], gd[EPT];
 #pragma unroll
@@ -75,19 +83,19 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         }
     }
 
-    for (int mv = 0; mv < moves; ++mv) {
+    int mv = 0;
+    for (; mv < moves; ++mv) {
         // ---- best up / best down of the row
-        Best bu = {NEG, 0x7fffffff}, bd = {NEG, 0x7fffffff};
+        Best bu = {NEG, 0x7fffffff, 0.0f}, bd = {NEG, 0x7fffffff, 0.0f};
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int j = t + 256 * e;
-            if (gu[e] > bu.v) bu = {gu[e], j};
-            if (gd[e] > bd.v) bd = {gd[e], j};
+            if (gu[e] > bu.v) bu = {gu[e], j, q[e]};
+            if (gd[e] > bd.v) bd = {gd[e], j, q[e]};
         }
         bu = wave_best(bu);
         bd = wave_best(bd);
-        __syncthreads();  // previous move's readers of the reduction slots are done
-        if (lane == 0) {
+        if (lane == 0) {  // (the previous move's readers of these slots passed the barriers of its sum)
             red_up[wave] = bu;
             red_dn[wave] = bd;
         }
@@ -101,31 +109,27 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         if (!go_up && !go_down) break;  // uniform: nothing can change in later moves either
         const int c = go_up ? bu.j : bd.j;
         const int ce = c >> 8, ct = c & 255;  // owner slot / thread of column c
-
-        // ---- stream row c of H: interaction sum with the OLD Q, and part 2 off the moved column
-        const float *hrow = H + (size_t)c * n;
-        float q_old = 0.0f;
-        if (t == ct) {
-#pragma unroll
-            for (int e = 0; e < EPT; ++e)
-                if (e == ce) q_old = q[e];
-        }
-        // broadcast q_old through LDS
-        if (t == ct) red_s[0] = q_old;
-        __syncthreads();
-        q_old = red_s[0];
-        __syncthreads();
+        const float q_old = go_up ? bu.q : bd.q;
         const float q_new = go_up ? cand_up(q_old, g) : cand_down(q_old, g);
+        // A "move" onto the value the weight already has (the up-candidate of the top level is the top level; a
+        // rounding residue can leave such a candidate a positive gain): the reference carries it out, and every
+        // term of its gain update (obq.py:322-334) is then a product with a zero difference -- Q and the gains stay as
+        // they are, so it repeats the same non-move until the moves run out.  Same final state: stop here.
+        if (q_new == q_old) break;
+        if (trace && t == 0) trace[(size_t)row * moves + mv] = 2 * c + (go_up ? 1 : 0);
+
+        // ---- stream row c of H: the products of the interaction sum with the OLD Q (obq.py:328), and part 2
+        //      off the moved column
+        const float *hrow = H + (size_t)c * n;
         const float two_dq = 2.0f * (q_old - q_new);
 
-        float s = 0.0f;
         float h_cc = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int j = t + 256 * e;
             if (j < n) {
                 const float h = hrow[j];
-                s = s + (q[e] - w[e]) * h;  // Q still holds the old value at column c
+                terms[heap_sum_pos(j)] = (q[e] - w[e]) * h;  // Q still holds the old value at column c
                 if (j == c) {
                     h_cc = h;
                 } else {
@@ -135,11 +139,8 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
                 }
             }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
-        if (lane == 0) red_s[wave] = s;
-        __syncthreads();
-        s = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+        // np.sum(axis=-1) of the products, in NumPy's pairwise order: the sum feeds a gain that later moves compare
+        const float s = heap_sum(plan, terms, n);
 
         // ---- the moved column: diagonal term, interaction part 1, then part 2 (obq.py:322-334)
         if (t == ct) {
@@ -165,6 +166,8 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
             }
         }
     }
+    if (trace && t == 0)
+        for (; mv < moves; ++mv) trace[(size_t)row * moves + mv] = -1;
 
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -181,8 +184,8 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 using namespace slk;
 
 extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
-                                double hi, const float *table, int moves, uint8_t *idx, void *workspace, size_t ws_bytes,
-                                slk_stream_t stream) {
+                                double hi, const float *table, int moves, uint8_t *idx, int *trace, void *workspace,
+                                size_t ws_bytes, slk_stream_t stream) {
     SLK_REQUIRE(W && Q && H && R > 0 && n > 0 && moves >= 0, "bad arguments");
     SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
     SLK_REQUIRE(idx == nullptr || levels <= 256, "uint8 indices need levels <= 256");
@@ -202,9 +205,13 @@ extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R,
     SLK_RUN("extract_diag", 0, 8.0 * n, s, k_extract_diag<<<(n + 255) / 256, 256, 0, s>>>(H, n, hdiag));
     const Grid g = make_grid(levels, lo, hi, table);
     const int ept = (n + 255) / 256;
-#define SLK_LS(E)                                                                                     \
-    SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,             \
-            k_local_search<E><<<R, 256, 0, s>>>(W, Q, H, G, hdiag, R, n, g, moves, idx))
+    const size_t lds = (size_t)(n + 8 * (n / 128) + 8) * sizeof(float);  // heap_sum_floats(n)
+#define SLK_LS(E)                                                                                          \
+    do {                                                                                                   \
+        SLK_LDS_OPT_IN(k_local_search<E>, lds);                                                            \
+        SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,              \
+                k_local_search<E><<<R, 256, lds, s>>>(W, Q, H, G, hdiag, R, n, g, moves, idx, trace));     \
+    } while (0)
     if (ept <= 4) SLK_LS(4);
     else if (ept <= 8) SLK_LS(8);
     else if (ept <= 16) SLK_LS(16);

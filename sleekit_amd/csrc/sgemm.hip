@@ -551,9 +551,9 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     // K split of the bfloat16 kernel for few rows (see the kernel): the largest chunk that still gives >= 512 workgroups
     const int n_rt = (R + T32 - 1) / T32;
     int cb = 0, n_slots = n_tiles;
-    if (G == nullptr && n_rt * n_tiles < 512 && getenv("SLK_NO_ERROR_SPLITK") == nullptr) {
-        const char *force = getenv("SLK_ERROR_CB");
-        for (int c = force ? atoi(force) : 16; c >= 2; c >>= 1) {
+    if (G == nullptr && n_rt * n_tiles < 512 && !opt(OPT_NO_ERROR_SPLITK)) {
+        const int force = opt(OPT_ERROR_CB);
+        for (int c = force ? force : 16; c >= 2; c >>= 1) {
             int slots = 0;
             for (int x = 0; x < n_tiles; ++x) slots += (x + c) / c;
             if (slots > 4 * n_tiles) break;
@@ -575,7 +575,7 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     bool aligned = ((uintptr_t)W | (uintptr_t)Q) % 16 == 0;
     for (int b = 0; b < batch; ++b) aligned = aligned && (uintptr_t)Hs[b] % 16 == 0;
     const int vec_ok = n % 4 == 0 && aligned;
-    const bool try_sym = getenv("SLK_NO_SYM_ERROR") == nullptr;  // (with G too: the bfloat16 kernel needs H symmetric)
+    const bool try_sym = !opt(OPT_NO_SYM_ERROR);  // (with G too: the bfloat16 kernel needs H symmetric)
     if (try_sym && sym_known) {
         sym = const_cast<int *>(sym_known);  // verdicts computed elsewhere (slk_symmetry_flag), read only from here on
     } else if (try_sym) {
@@ -587,7 +587,7 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     // the symmetric case goes to the bfloat16 x 3 kernel when the shape allows (16-byte loads, whole tiles of columns)
     const size_t d_plane = (size_t)n_rt * T32 * n;  // rows padded to whole tiles
     unsigned short *Dp = ws.take<unsigned short>(3 * d_plane), *Hp = ws.take<unsigned short>(3 * (size_t)n * n * batch);
-    const int bf16_ok = try_sym && vec_ok && n % T32 == 0 && Dp && Hp && getenv("SLK_NO_BF16_ERROR") == nullptr;
+    const int bf16_ok = try_sym && vec_ok && n % T32 == 0 && Dp && Hp && !opt(OPT_NO_BF16_ERROR);
     if (batch > 1 && !(Dp && Hp)) {
         set_error("workspace too small for the operand planes of %d layers (slk_workspace_bytes_batch)", batch);
         return SLK_E_WS;
@@ -600,15 +600,9 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     };
     // algorithmic flops: the definition (2 R n^2) whichever way they are obtained
     if (bf16_ok) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_error_tiles_bf16<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TileBf16Smem)));
-            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_error_tiles_bf16<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TileBf16DmaSmem)));
-            attr_set = true;
-        }
-        const int dma = getenv("SLK_NO_BF16_DMA") == nullptr;  // operands to LDS by global_load_lds (swizzled planes)
+        SLK_LDS_OPT_IN(k_error_tiles_bf16<false>, sizeof(TileBf16Smem));
+        SLK_LDS_OPT_IN(k_error_tiles_bf16<true>, sizeof(TileBf16DmaSmem));
+        const int dma = !opt(OPT_NO_BF16_DMA);  // operands to LDS by global_load_lds (swizzled planes)
         SLK_RUN("error_split", 0, 14.0 * R * n, s,
                 k_split3<<<2048, 256, 0, s>>>(W, Q, R, n, Dp, d_plane, batch == 1 ? sym : nullptr, dma));
         for (int b = 0; b < batch; ++b)
@@ -671,16 +665,10 @@ int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, 
     // bfloat16 x 3 path: whole tiles of features, and room for the planes of at least 32 tokens
     Arena ws(workspace, ws_bytes);
     const size_t room = workspace && ws_bytes > 4096 ? (ws_bytes - 4096) / ((size_t)6 * n) / 32 * 32 : 0;  // tokens per chunk
-    if (n % T32 == 0 && room >= 32 && getenv("SLK_NO_BF16_HESSIAN") == nullptr) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hessian_tiles_bf16<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TileBf16Smem)));
-            SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hessian_tiles_bf16<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TileBf16DmaSmem)));
-            attr_set = true;
-        }
-        const int dma = getenv("SLK_NO_BF16_DMA") == nullptr;
+    if (n % T32 == 0 && room >= 32 && !opt(OPT_NO_BF16_HESSIAN)) {
+        SLK_LDS_OPT_IN(k_hessian_tiles_bf16<false>, sizeof(TileBf16Smem));
+        SLK_LDS_OPT_IN(k_hessian_tiles_bf16<true>, sizeof(TileBf16DmaSmem));
+        const int dma = !opt(OPT_NO_BF16_DMA);
         const int chunk = (int)(room < (size_t)((T + 31) / 32 * 32) ? room : (size_t)((T + 31) / 32 * 32));
         unsigned short *Xp = ws.take<unsigned short>((size_t)3 * n * chunk);
         const int m = n / T32, total = m * (m + 1) / 2;

@@ -72,10 +72,10 @@ def require_uniform(quantizer):
 class LayerResult:
     """Device tensors produced for one layer."""
 
-    __slots__ = ("Q", "idx", "order", "U", "info", "E")
+    __slots__ = ("Q", "idx", "order", "U", "info", "E", "ls_trace")
 
     def __init__(self):
-        self.Q = self.idx = self.order = self.U = self.info = self.E = None
+        self.Q = self.idx = self.order = self.U = self.info = self.E = self.ls_trace = None
 
 
 def factorize(H, n, damp, mode, miss=None, keep=None):
@@ -176,17 +176,20 @@ def symmetry_flag(H):
     return flag
 
 
-def local_search(W, Q, H, cb_abi, moves, idx=None):
-    """In place on Q (and idx)."""
+def local_search(W, Q, H, cb_abi, moves, idx=None, want_trace=False):
+    """In place on Q (and idx).  want_trace: returns the (R, moves) int32 record of the moves taken
+    (2 * column + up, -1 = none), see slk_local_search."""
     R, n = W.shape
     levels, lo, hi, table = cb_abi
     ws, ws_bytes = dev.workspace(R, n)
+    trace = torch.empty((R, int(moves)), dtype=torch.int32, device=W.device) if want_trace else None
     _lib.check(
         _lib.lib.slk_local_search(
-            dev.ptr(W), dev.ptr(Q), dev.ptr(H), R, n, levels, lo, hi, dev.ptr(table), int(moves), dev.ptr(idx), dev.ptr(ws),
-            ws_bytes, dev.stream_handle(),
+            dev.ptr(W), dev.ptr(Q), dev.ptr(H), R, n, levels, lo, hi, dev.ptr(table), int(moves), dev.ptr(idx), dev.ptr(trace),
+            dev.ptr(ws), ws_bytes, dev.stream_handle(),
         )
     )
+    return trace
 
 
 def rows_divide(x, scale, invert=False):
@@ -225,7 +228,7 @@ def row_errors(W, Q, H, want_G=False):
 
 def quantize_layer(
     W, H, quantizer, scale=None, act_order="diag", damp=0.01, nb_ls_moves=0, min_block_size=32, num_blocks=8,
-    factor=None, unscale=True, want_idx=True,
+    factor=None, unscale=True, want_idx=True, want_ls_trace=False,
 ):
     """One layer through the whole path, on device tensors.
 
@@ -233,7 +236,7 @@ def quantize_layer(
     re-uses a factor computed elsewhere (another GPU: see sleekit_amd.dist).  Returns a
     LayerResult whose Q is de-scaled when `scale` is given and `unscale` is true
     (sleekit/scaling.py:58-81), else the codebook values in the scaled domain
-    (sleekit/obq.py:169-217).
+    (sleekit/obq.py:169-217).  want_ls_trace: res.ls_trace = the local search's moves (slk_local_search).
     """
     assert W.ndim == 2
     assert H.ndim == 2
@@ -261,7 +264,7 @@ def quantize_layer(
     fused = scale is not None and unscale and nb_ls_moves == 0 and loop_scale is not None
     res.Q, res.idx, _ = run_loop(Ws, loop_scale, res.order, res.U, cb_abi, min_block_size, num_blocks, want_idx, unscale=fused)
     if nb_ls_moves > 0:
-        local_search(Ws, res.Q, H, cb_abi, nb_ls_moves, res.idx)
+        res.ls_trace = local_search(Ws, res.Q, H, cb_abi, nb_ls_moves, res.idx, want_trace=want_ls_trace)
     if scale is not None and unscale and not fused:
         res.Q = rows_divide(res.Q, scale, invert=True)
     return res

@@ -34,6 +34,11 @@ def large_cases():
         return json.load(f)["cases"]
 
 
+@pytest.fixture(scope="session")
+def ls_traces():
+    return np.load(os.path.join(GOLDEN, "ls_traces.npz"))
+
+
 def parse_case(name):
     """'r64_n96_s2001_N8_diag_ls10[_strip_d0.03]' -> dict."""
     p = name.split("_")
@@ -43,3 +48,32 @@ def parse_case(name):
         d["strip"] = True
         d["damp"] = float(p[7][1:])
     return d
+
+
+class _Options:
+    """setenv / delenv look-alikes over slk_set_option: the library reads SLK_* environment switches once, at its
+    first use, so tests flip them through the C ABI; everything touched is restored afterwards."""
+
+    def __init__(self):
+        from sleekit_amd import _lib
+
+        self._lib, self._old = _lib, {}
+
+    def setenv(self, name, value):
+        if name not in self._old:
+            self._old[name] = self._lib.lib.slk_get_option(name.encode())
+        self._lib.set_option(name, int(value))
+
+    def delenv(self, name, raising=True):
+        self.setenv(name, 0)
+
+    def restore(self):
+        for name, value in self._old.items():
+            self._lib.set_option(name, value)
+
+
+@pytest.fixture
+def slkopt():
+    o = _Options()
+    yield o
+    o.restore()

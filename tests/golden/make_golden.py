@@ -12,6 +12,10 @@ reference's outputs:
     small_cases.npz   full outputs (u8 indices, order, row errors, ...) of small layers
     pieces.npz        known-answer vectors of the helper functions on the path
     large_cases.json  SHA-256 of indices + float32 errors of BASELINE-sized layers
+    ls_traces.npz     for every case with local-search moves: the reference's sequence of moves and how close each
+                      decision was, for the rows that came near a tie (oracle/obq_ref.py: move_record), plus a
+                      per-row hash of the indices of the large cases -- what lets a parity test PROVE that a row
+                      which differs after local search differs because a near-tie fell the other way
 
 Only data is written: inputs and expected outputs.  No reference source text is
 copied.  The fixtures record the NumPy/BLAS versions because the float64
@@ -44,7 +48,7 @@ def sha(a):
     return hashlib.sha256(a.tobytes()).hexdigest()
 
 
-def run_reference(L, levels, order, damp, moves, strip_mean=False):
+def run_reference(L, levels, order, damp, moves, strip_mean=False, want_records=False):
     cb = UniformCodebook(levels, -1, 1)
     W, H, sc = L["W"], L["H"], L["scale"]
     if strip_mean:
@@ -52,7 +56,79 @@ def run_reference(L, levels, order, damp, moves, strip_mean=False):
     out = ref_scaling.quantize_with_scaling(W, sc, cb, H, act_order=order, damp=damp, nb_ls_moves=moves)
     idx = cb.quantize_index(ref_scaling.apply_scaling(out, sc, 0))
     rows = ref_obq.channelwise_error(W, out, H)
-    return dict(out=out, idx=idx, row_err=rows, err=ref_obq.quantization_error(W, out, H), H_used=H)
+    res = dict(out=out, idx=idx, row_err=rows, err=ref_obq.quantization_error(W, out, H), H_used=H)
+    if want_records and moves > 0:
+        res["records"] = local_search_records(W, H, sc, cb, order, damp, moves, out)
+    return res
+
+
+def local_search_records(W, H, sc, cb, order, damp, moves, expected_out):
+    """The reference's local search driven move by move (its own LocalSearchQuantizer, obq.py:234-346, exactly as
+    quantize_local_search drives it), reading its gains before every move.  The result must be the one-call
+    result bit for bit, or the records describe something else."""
+    from oracle import obq_ref  # move_record only inspects arrays: no oracle arithmetic enters the fixture's moves
+
+    quant = ref_scaling.apply_scaling(W, sc, 0)
+    Q0 = ref_obq.quantize_opt(quant, H, cb, act_order=order, damp=damp, nb_ls_moves=0)
+    W32, H32 = quant.astype(np.float32), H.astype(np.float32)  # what quantize_opt hands to the search (obq.py:195-196, 216)
+    ls = ref_obq.LocalSearchQuantizer(W32, Q0, H32, cb)
+    noise = obq_ref.gain_noise_scale(W32, Q0, H32)
+    records = []
+    for _ in range(moves):
+        records.append(obq_ref.move_record(ls.gain_up, ls.gain_down, ls.Q_up - ls.Q, ls.Q_down - ls.Q, noise))
+        ls.do_move()
+    assert np.array_equal(ref_scaling.apply_scaling(ls.Q, 1 / sc, 0), expected_out), "instrumented drive != quantize_with_scaling"
+    return records
+
+
+# Rows whose closest decision came within this many roundings (move_record's ratio) are kept with their full records.
+# The worst-case bound on the difference of two float32 GEMMs is ~2 n roundings, but at that width nearly every row
+# would qualify (typical margins are 1e3 ... 1e5); errors of real GEMMs are a few roundings, and so is the bound the
+# parity tests apply (tests/test_gpu_parity.py: LS_NEAR_TIE).
+NEAR_TIE_LIMIT = 64
+
+
+def row_hashes(idx):
+    return np.array([int.from_bytes(hashlib.sha256(np.ascontiguousarray(r).tobytes()).digest()[:8], "little") for r in idx],
+                    dtype=np.uint64)
+
+
+def ls_traces():
+    """Local-search evidence for every fixture case with moves (small_cases.npz and large_cases.json alike)."""
+    from oracle import obq_ref
+
+    T = {}
+    names = []
+
+    def add(name, L, levels, order, damp, moves, strip, large):
+        r = run_reference(L, levels, order, damp, moves, strip_mean=strip, want_records=True)
+        n = L["W"].shape[1]
+        s = obq_ref.near_tie_summary(r["records"], NEAR_TIE_LIMIT)
+        for k, v in s.items():
+            T[f"{name}/{k}"] = v
+        T[f"{name}/row_hash"] = row_hashes(r["idx"])
+        T[f"{name}/sha_idx"] = np.array(sha(r["idx"]))
+        names.append(name)
+        allr = np.stack([x["ratio"] for x in r["records"]], axis=1)
+        print(f"{name}: {len(s['rows'])} near-tie rows of {L['W'].shape[0]}, smallest ratio {allr.min():.3g} (n = {n})", flush=True)
+
+    shapes = [(8, 16), (64, 96), (128, 256), (96, 172)]
+    seed = 2000
+    for R, n in shapes:
+        L = synth.make_layer(R, n, seed)
+        for levels in (2, 3, 4, 8):
+            for order in ("diag", "none", "sqerr"):
+                add(f"r{R}_n{n}_s{seed}_N{levels}_{order}_ls10", L, levels, order, 0.01, 10, False, False)
+        seed += 1
+    L = synth.make_layer(256, 768, 2010)
+    for levels in (3, 8):
+        add(f"r256_n768_s2010_N{levels}_diag_ls10", L, levels, "diag", 0.01, 10, False, False)
+    for R, n, seed, levels, order, damp, moves, strip in LARGE:
+        if moves > 0:
+            add(f"r{R}_n{n}_s{seed}_N{levels}_{order}_ls{moves}", synth.make_layer(R, n, seed), levels, order, damp, moves, strip, True)
+    T["names"] = np.array(names)
+    T["near_tie_limit"] = np.int64(NEAR_TIE_LIMIT)
+    return T
 
 
 def small_cases():
@@ -243,6 +319,9 @@ LARGE = [
     (4096, 1024, 1006, 8, "diag", 0.01, 10, False),
     (4096, 4096, 1007, 8, "diag", 0.01, 0, False),  # headline
     (512, 11008, 1008, 4, "diag", 0.01, 0, False),  # cfg5 row shard (1/8 of 4096 rows)
+    (3072, 1024, 1009, 8, "diag", 0.01, 10, False),  # cfg4 (BLOOM-560M qkv) + 10 moves
+    (1024, 4096, 1010, 8, "diag", 0.01, 10, False),  # cfg4 (BLOOM-560M 4h->h) + 10 moves
+    (4096, 4096, 1011, 8, "diag", 0.01, 10, False),  # headline shape + 10 moves
 ]
 
 
@@ -250,7 +329,7 @@ def large_cases(selected=None):
     out = []
     for spec in LARGE:
         R, n, seed, levels, order, damp, moves, strip = spec
-        if selected and f"{R}x{n}" not in selected:
+        if selected and f"{R}x{n}" not in selected and f"{R}x{n}s{seed}" not in selected:
             continue
         t0 = time.time()
         L = synth.make_layer(R, n, seed)
@@ -272,7 +351,9 @@ def large_cases(selected=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true", help="also (re)generate large_cases.json (minutes)")
-    ap.add_argument("--only", nargs="*", help="large shapes to run, e.g. 768x768")
+    ap.add_argument("--only", nargs="*", help="large shapes to run, e.g. 768x768 (or 4096x4096s1011 for one seed)")
+    ap.add_argument("--skip-small", action="store_true", help="leave small_cases.npz and pieces.npz as they are")
+    ap.add_argument("--ls-traces", action="store_true", help="(re)generate ls_traces.npz (a minute: runs the large LS cases too)")
     args = ap.parse_args()
 
     env = dict(numpy=np.__version__, python=sys.version.split()[0], cpu_count=os.cpu_count())
@@ -281,10 +362,13 @@ def main():
     except Exception:
         env["blas"] = "unknown"
 
-    np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **small_cases())
-    np.savez_compressed(os.path.join(HERE, "pieces.npz"), **pieces())
-    with open(os.path.join(HERE, "environment.json"), "w") as f:
-        json.dump(env, f, indent=1)
+    if not args.skip_small:
+        np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **small_cases())
+        np.savez_compressed(os.path.join(HERE, "pieces.npz"), **pieces())
+        with open(os.path.join(HERE, "environment.json"), "w") as f:
+            json.dump(env, f, indent=1)
+    if args.ls_traces:
+        np.savez_compressed(os.path.join(HERE, "ls_traces.npz"), **ls_traces())
     if args.large:
         path = os.path.join(HERE, "large_cases.json")
         recs = large_cases(args.only)

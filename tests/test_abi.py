@@ -33,12 +33,30 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_sizes():
     from sleekit_amd import _lib
 
-    assert _lib.lib.slk_abi_version() == 3
+    assert _lib.lib.slk_abi_version() == 4
     assert _lib.lib.slk_factor_ld(1) == 64 and _lib.lib.slk_factor_ld(64) == 64 and _lib.lib.slk_factor_ld(11008) == 11008
     assert _lib.lib.slk_factor_ld(1100) == 1152
     # 4096 x 4096: two float64 n x n scratch matrices dominate
     assert _lib.lib.slk_workspace_bytes(4096, 4096) >= 2 * 4096 * 4096 * 8
     assert _lib.lib.slk_workspace_bytes(512, 11008) >= 2 * 11008 * 11008 * 8
+
+
+def test_options_are_read_once_and_set_through_the_abi():
+    """SLK_* environment switches are read at first use only; afterwards slk_set_option is the way."""
+    from sleekit_amd import _lib
+
+    assert _lib.lib.slk_get_option(b"no_window2") in (0, 1)
+    old = _lib.lib.slk_get_option(b"NO_WINDOW2")
+    os.environ["SLK_NO_WINDOW2"] = "1" if not old else "0"   # too late: not looked at again
+    try:
+        assert _lib.lib.slk_get_option(b"SLK_NO_WINDOW2") == old
+        with _lib.option("no_window2", 5):
+            assert _lib.lib.slk_get_option(b"no_window2") == 5
+        assert _lib.lib.slk_get_option(b"no_window2") == old
+    finally:
+        del os.environ["SLK_NO_WINDOW2"]
+    assert _lib.lib.slk_set_option(b"no_such_switch", 1) == _lib.E_ARG
+    assert b"unknown option" in _lib.lib.slk_last_error()
 
 
 def test_argument_errors_do_not_touch_the_gpu():

@@ -228,7 +228,7 @@ def test_loop_blockings_match_oracle(amd, min_block, num_blocks):
 
 @pytest.mark.parametrize("n", [96, 768, 1024, 1376, 3072, 4096])
 @pytest.mark.parametrize("odd_diagonal", [False, True])
-def test_window_kernels_agree(amd, n, odd_diagonal, monkeypatch):
+def test_window_kernels_agree(amd, n, odd_diagonal, slkopt):
     """The standard-schedule window kernel (row-independent chain waves, 4x4x4 MFMA local updates,
     helper waves) against the general one (16-row MFMA, barriers), bit for bit on Q and E: every
     BASELINE width (one- and two-leaf periods, 32 + 16 and 5 x 32 + 12 leaves), a ragged last row
@@ -243,9 +243,9 @@ def test_window_kernels_agree(amd, n, odd_diagonal, monkeypatch):
     out = []
     for general in (False, True):
         if general:
-            monkeypatch.setenv("SLK_NO_WINDOW2", "1")
+            slkopt.setenv("SLK_NO_WINDOW2", "1")
         else:
-            monkeypatch.delenv("SLK_NO_WINDOW2", raising=False)
+            slkopt.delenv("SLK_NO_WINDOW2", raising=False)
         Q, E = W.copy(), np.zeros_like(W)
         amd.obq._quantize_opt_block(Q, E, U, cb, 32, 8)
         out.append((Q, E))
@@ -331,14 +331,14 @@ def test_orders_from_the_inverse_diagonal(amd, order):
 
 
 @pytest.mark.parametrize("staged", [False, True])
-def test_hessian_accumulate_bf16_path(amd, monkeypatch, staged):
+def test_hessian_accumulate_bf16_path(amd, slkopt, staged):
     """statistics.py:76-87 with a feature count that is a multiple of 128: X^T X on the bfloat16 MFMA (three
     pieces per operand).  A ragged token count, two batches (running-mean factor), and a workspace so small
     that the tokens go in chunks of 32 -- each against float64, to float32 GEMM tolerance.  Both ways of bringing
     the operands to LDS: global_load_lds of swizzled planes (default) and staging through registers."""
     import torch
     if staged:
-        monkeypatch.setenv("SLK_NO_BF16_DMA", "1")
+        slkopt.setenv("SLK_NO_BF16_DMA", "1")
     from sleekit_amd import _lib, _device as dev
 
     rng = np.random.default_rng(21)
@@ -385,7 +385,7 @@ def test_integration_stub_runs(amd):
     assert np.array_equal(got.cpu().numpy(), amd.obq.quantize_opt(Ws, L["H"], cb))
 
 
-def test_layer_error_bf16_path(amd, monkeypatch):
+def test_layer_error_bf16_path(amd, slkopt):
     """The layer error of a symmetric Hessian runs on the bfloat16 MFMA with three pieces per operand
     (six products): every row within 1e-5 of the float64 value, like the float32 kernel it replaces --
     ragged row count, float32-MFMA path forced for comparison, and an asymmetric H (float32 kernel, all of H)."""
@@ -400,23 +400,23 @@ def test_layer_error_bf16_path(amd, monkeypatch):
     want = ((D @ H.astype(np.float64)) * D).sum(axis=1)
     got = amd.obq.channelwise_error(W, Q, H)
     np.testing.assert_allclose(got, want, rtol=1e-5)
-    monkeypatch.setenv("SLK_NO_BF16_DMA", "1")  # operands staged through registers instead of global_load_lds
+    slkopt.setenv("SLK_NO_BF16_DMA", "1")  # operands staged through registers instead of global_load_lds
     np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, H), got, rtol=2e-6)
-    monkeypatch.delenv("SLK_NO_BF16_DMA")
-    monkeypatch.setenv("SLK_NO_BF16_ERROR", "1")
+    slkopt.delenv("SLK_NO_BF16_DMA")
+    slkopt.setenv("SLK_NO_BF16_ERROR", "1")
     got32 = amd.obq.channelwise_error(W, Q, H)
-    monkeypatch.delenv("SLK_NO_BF16_ERROR")
+    slkopt.delenv("SLK_NO_BF16_ERROR")
     np.testing.assert_allclose(got32, want, rtol=1e-5)
     np.testing.assert_allclose(got, got32, rtol=2e-6)
     # few rows: K is cut into chunks so that the tiles fill the chip (a row shard of a multi-GPU run); every chunk
     # size, and the uncut kernel, within rounding of each other
     for chunk in ("2", "4", "8", "16"):
-        monkeypatch.setenv("SLK_ERROR_CB", chunk)
+        slkopt.setenv("SLK_ERROR_CB", chunk)
         np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, H), want, rtol=1e-5)
-    monkeypatch.delenv("SLK_ERROR_CB")
-    monkeypatch.setenv("SLK_NO_ERROR_SPLITK", "1")
+    slkopt.delenv("SLK_ERROR_CB")
+    slkopt.setenv("SLK_NO_ERROR_SPLITK", "1")
     whole = amd.obq.channelwise_error(W, Q, H)
-    monkeypatch.delenv("SLK_NO_ERROR_SPLITK")
+    slkopt.delenv("SLK_NO_ERROR_SPLITK")
     np.testing.assert_allclose(whole, want, rtol=1e-5)
     np.testing.assert_allclose(got, whole, rtol=2e-6)
     Ha = H.copy()
@@ -802,7 +802,7 @@ def test_graph_replay_of_a_layer(amd):
 
 
 @pytest.mark.parametrize("n", [768, 1024, 1536, 2048, 3072, 4096])
-def test_scale_search_regular_tree(amd, monkeypatch, n):
+def test_scale_search_regular_tree(amd, slkopt, n):
     """Row lengths whose NumPy summation tree is regular (2^k leaves of <= 128 elements) take the chain-per-thread
     search kernel: same scales, bit for bit, as NumPy (the oracle) and as the general kernel."""
     R = 12
@@ -813,12 +813,12 @@ def test_scale_search_regular_tree(amd, monkeypatch, n):
     for H in (None, hd):
         got = amd.scaling.compute_min_mse_scaling(W, cb, H=H, grid_size=37)
         assert np.array_equal(got, scaling_ref.best_grid_scale(W, g, H=H, grid_size=37)), (n, H is None)
-        monkeypatch.setenv("SLK_NO_REGULAR_SEARCH", "1")
+        slkopt.setenv("SLK_NO_REGULAR_SEARCH", "1")
         assert np.array_equal(got, amd.scaling.compute_min_mse_scaling(W, cb, H=H, grid_size=37))
-        monkeypatch.delenv("SLK_NO_REGULAR_SEARCH")
+        slkopt.delenv("SLK_NO_REGULAR_SEARCH")
 
 
-def test_scale_search_fast_division(amd, monkeypatch):
+def test_scale_search_fast_division(amd, slkopt):
     """The regular-tree search replaces its three float32 divisions per element by Markstein's fma sequence where
     that is exact: same choices as with true divides and as NumPy, on rows with a wide dynamic range, zeros,
     denormals, and divisors whose significand is all ones (sent to the true divide)."""
@@ -834,9 +834,9 @@ def test_scale_search_fast_division(amd, monkeypatch):
         cb = amd.codebook.UniformCodebook(levels, lo, hi)
         for H in (None, hd):
             got = amd.scaling.compute_min_mse_scaling(W, cb, H=H, grid_size=150)
-            monkeypatch.setenv("SLK_NO_FAST_SEARCH_DIV", "1")
+            slkopt.setenv("SLK_NO_FAST_SEARCH_DIV", "1")
             slow = amd.scaling.compute_min_mse_scaling(W, cb, H=H, grid_size=150)
-            monkeypatch.delenv("SLK_NO_FAST_SEARCH_DIV")
+            slkopt.delenv("SLK_NO_FAST_SEARCH_DIV")
             assert np.array_equal(got, slow), (levels, H is None)
             with np.errstate(over="ignore"):  # the 1e30 entries square to inf, in NumPy as on the GPU
                 want = scaling_ref.best_grid_scale(W, g, H=H, grid_size=150)

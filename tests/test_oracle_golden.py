@@ -59,6 +59,32 @@ def test_small_cases_bit_exact(small_cases):
         assert np.float32(err) == small_cases[name + "/err"], name
 
 
+def test_local_search_records_match_the_reference(ls_traces):
+    """ls_traces.npz holds the REAL reference's sequence of local-search moves (its own LocalSearchQuantizer driven
+    move by move) for the rows that came near a tie.  The oracle's search, instrumented the same way, must take
+    the same moves with the same margins: this pins the records the GPU parity tests rely on."""
+    names = [str(x) for x in ls_traces["names"]]
+    assert len(names) >= 50
+    limit = int(ls_traces["near_tie_limit"])
+    seen = 0
+    for name in names:
+        c = parse_case(name)
+        if c["R"] * c["n"] > 256 * 768:
+            continue  # BASELINE-sized: seconds to minutes each on the CPU; the GPU suite holds their hashes
+        L = layer(c["R"], c["n"], c["seed"])
+        g = grid.UniformGrid(c["levels"], -1, 1)
+        Ws = scaling_ref.divide_rows(L["W"], L["scale"], 0)
+        Q0 = obq_ref.quantize_layer(Ws, L["H"], g, c["order"], c["damp"], 0)
+        records = []
+        obq_ref.local_search(Ws.astype(np.float32), Q0, L["H"].astype(np.float32), g, c["moves"], records)
+        s = obq_ref.near_tie_summary(records, limit)
+        for k in ("rows", "choice", "runner"):
+            assert np.array_equal(s[k], ls_traces[f"{name}/{k}"]), (name, k)
+        assert np.array_equal(s["ratio"], ls_traces[f"{name}/ratio"]), name
+        seen += 1
+    assert seen >= 50
+
+
 @pytest.mark.parametrize("levels", [2, 3, 4, 8, 16, 256, "asym"])
 def test_uniform_grid_known_answers(pieces, levels):
     x = pieces["cb/x"]

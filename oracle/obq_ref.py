@@ -188,9 +188,10 @@ def run_schedule(Q, E, U, grid, ops):
 
 
 def quantize_layer(
-    W, H, grid, order_mode="diag", damp=0.01, ls_moves=0, min_block=32, num_blocks=8, ties="numpy"
+    W, H, grid, order_mode="diag", damp=0.01, ls_moves=0, min_block=32, num_blocks=8, ties="numpy", ls_records=None
 ):
-    """GPTQ-style quantization of one layer (obq.py:169-217). Returns grid values, float32."""
+    """GPTQ-style quantization of one layer (obq.py:169-217). Returns grid values, float32.
+    ls_records: see local_search."""
     assert W.ndim == 2 and H.ndim == 2
     assert H.shape[0] == H.shape[1] == W.shape[1]
     assert min_block >= 1
@@ -212,7 +213,7 @@ def quantize_layer(
     back = np.argsort(order)
     W0 = Wp[:, back]
     Q = Q[:, back]
-    return local_search(W0, Q, H, grid, ls_moves)
+    return local_search(W0, Q, H, grid, ls_moves, ls_records)
 
 
 def quantize_layer_debug(W, H, grid, order_mode="diag", damp=0.01, min_block=32, num_blocks=8):

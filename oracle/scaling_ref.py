@@ -43,7 +43,7 @@ def no_clip_scale(data, grid, axis=0):
     return np.maximum(scale, np.float32(1.0e-16))
 
 
-def quantize_scaled(data, scale, grid, H=None, order_mode="diag", damp=0.01, ls_moves=0, ties="numpy"):
+def quantize_scaled(data, scale, grid, H=None, order_mode="diag", damp=0.01, ls_moves=0, ties="numpy", ls_records=None):
     """Divide rows by `scale`, quantize (GPTQ loop when H is given), undo the scale.
 
     Note the un-scaling is a division by the float32 reciprocal (scaling.py:80),
@@ -52,7 +52,7 @@ def quantize_scaled(data, scale, grid, H=None, order_mode="diag", damp=0.01, ls_
     assert data.ndim == 2 and scale.ndim == 1 and data.shape[0] == scale.size
     q = divide_rows(data, scale, 0)
     if H is not None:
-        q = obq_ref.quantize_layer(q, H, grid, order_mode=order_mode, damp=damp, ls_moves=ls_moves, ties=ties)
+        q = obq_ref.quantize_layer(q, H, grid, order_mode=order_mode, damp=damp, ls_moves=ls_moves, ties=ties, ls_records=ls_records)
     else:
         q = grid(q)
     return divide_rows(q, 1 / scale, 0)

@@ -3,6 +3,7 @@ codebook, local search, unusual blockings -- small enough for the NumPy oracle t
 import numpy as np
 import pytest
 
+from ls_evidence import explain_rows
 from oracle import grid, obq_ref, scaling_ref
 
 pytestmark = pytest.mark.gpu
@@ -21,7 +22,9 @@ def amd():
         pass
 
     ns = NS()
-    ns.codebook, ns.obq, ns.scaling = codebook, obq, scaling
+    from sleekit_amd import engine
+
+    ns.codebook, ns.obq, ns.scaling, ns.engine = codebook, obq, scaling, engine
     return ns
 
 
@@ -55,16 +58,23 @@ def test_layer_against_oracle(amd, seed):
         if (np.diff(vals) <= 0).any():
             vals = np.linspace(-1, 1, c["levels"]).astype(np.float32)
         g, cb = grid.TableGrid(vals), amd.codebook.Codebook(vals)
-    want = scaling_ref.quantize_scaled(c["W"], c["scale"], g, c["H"], c["order"], c["damp"], c["moves"], ties="stable")
-    got = amd.scaling.quantize_with_scaling(c["W"], c["scale"], cb, c["H"], act_order=c["order"], damp=c["damp"], nb_ls_moves=c["moves"])
+    records = []
+    want = scaling_ref.quantize_scaled(c["W"], c["scale"], g, c["H"], c["order"], c["damp"], c["moves"], ties="stable", ls_records=records)
     if c["moves"] == 0:
+        got = amd.scaling.quantize_with_scaling(c["W"], c["scale"], cb, c["H"], act_order=c["order"], damp=c["damp"], nb_ls_moves=0)
         assert np.array_equal(got, want), {k: v for k, v in c.items() if k not in ("W", "H", "scale")}
-    else:  # local-search near-ties: rows may differ when two gains agree to float32 GEMM rounding
+    else:
+        # local search: bit-equal, or -- row by row -- a PROVEN near-tie of the oracle's own decision (ls_evidence.py)
+        import torch
+
+        W, H, sc = (torch.from_numpy(c[k]).cuda() for k in ("W", "H", "scale"))
+        res = amd.engine.quantize_layer(W, H, cb, sc, c["order"], c["damp"], c["moves"], want_ls_trace=True)
+        got = res.Q.cpu().numpy()
         bad = np.flatnonzero((got != want).any(axis=1))
-        assert len(bad) <= max(1, c["W"].shape[0] // 20), (len(bad), c["order"], c["levels"])
+        explain_rows(bad, res.ls_trace.cpu().numpy(), obq_ref.near_tie_summary(records, 64.0))
     e_got = amd.obq.quantization_error(c["W"], got, c["H"])
     e_want = obq_ref.mean_error(c["W"].astype(np.float32), want, c["H"])
-    assert abs(float(e_got) - float(e_want)) <= 1e-5 * abs(float(e_want)) + 1e-12 or c["moves"] > 0
+    assert abs(float(e_got) - float(e_want)) <= 1e-5 * abs(float(e_want)) + 1e-12 or (c["moves"] > 0 and len(bad))
 
 
 @pytest.mark.parametrize("seed", range(8))

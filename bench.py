@@ -1,25 +1,35 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mweights/s quantized (GPTQ 3-bit, 4096 x 4096 layers) on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One STEP = one pass of the hot path over a batch of `--layers` (default 8) synthetic
-4096 x 4096 layers, 3-bit uniform codebook, act_order="diag", damp=0.01, no local search
-(BASELINE.json's headline metric): per layer
-    scale -> damp + order + gather -> float64 factor -> blocked quantize/propagate loop -> un-scale
-    -> layer error (W - Qw) H (W - Qw)^T
+One STEP = one pass of the hot path over a batch of synthetic layers, every layer with inputs of its own:
+    default   8 layers 4096 x 4096, 3-bit uniform codebook, act_order="diag", damp=0.01, no local search
+              (BASELINE.json's headline metric)
+    --config  the layer stream of a BASELINE.json config, in MODEL order (SURVEY.md 8 preamble):
+              cfg2 OPT-125M  12 x {4 x 768^2, 3072x768, 768x3072}, 3 bit
+              cfg3 OPT-350M  24 x {4 x 1024^2, 4096x1024, 1024x4096}, 1.5 bit (3 levels), H - m m^T (inside the step)
+              cfg4 BLOOM-560M 24 x {3072x1024, 1024^2, 4096x1024, 1024x4096}, 3 bit + 10 local-search moves
+              cfg5 32 x (4096 x 11008), 2 bit
+per layer
+    [strip mean] -> scale -> damp + order + gather -> float64 factor -> blocked quantize/propagate loop
+    [-> local search] -> un-scale -> layer error (W - Qw) H (W - Qw)^T
 with W, H and the row scales resident in HBM before the clock starts.  N > 1 shards the
-rows of every layer across the ranks (sleekit_amd/dist.py); the factor of layer l is made by
-rank l mod N and broadcast once over RCCL.  Total work is the same at every N ("strong").
+rows of every layer across the ranks (sleekit_amd/dist.py); the factors are made by the ranks in turn and cross
+xGMI once, in one RCCL all-gather per round of N same-shaped layers.  Total work is the same at every N ("strong").
 
 The JSON line also carries
-  roofline      for the kernel with the largest share of the chip's time in the step (HIP events
-                 around every launch, on the launch stream: slk_profile_* in the C ABI; a launch of
-                 fewer than 256 workgroups counts for that share of its duration),
-                 achieved = ALGORITHMIC flops or bytes of its launches / their summed duration;
+  roofline      for the kernel with the largest share of the chip's time IN THE TIMED CONFIGURATION (HIP events
+                 around every launch, on the launch stream: slk_profile_* in the C ABI; a launch of fewer than 256
+                 workgroups counts for that share of its duration); achieved = ALGORITHMIC flops or bytes of its
+                 launches / their summed duration; `alone` = the same kernel in a single-stream pass (no other
+                 kernel shares the chip); `single_stream_leader` = the kernel that leads that pass, when another;
+  latency_ms_single_layer   one isolated layer, start to finish;
+  asymmetric_H  the same workload with Hessians made by torch `X.T @ X` (not bit-symmetric, like the experiments' dumps):
+                 the layer error then cannot halve its work;
   cpu_baseline  the NumPy oracle (bit-identical to the reference, tests/test_oracle_golden.py)
-                 timed on this host for one 4096 x 4096 layer, rank 0, N = 1 only.
+                 timed on this host for one layer of the workload, rank 0, N = 1 only.
 """
 
 import argparse
@@ -53,20 +63,33 @@ KERNEL_DTYPE = {
     "error_gemm": "mfma_f32", "error_gemm_bf16": "mfma_bf16", "hessian_syrk": "mfma_f32",
 }
 
+# BASELINE.json configs as layer streams in model order (shapes from results/compare_3b.csv's layer names)
+WORKLOADS = {
+    "cfg2": dict(name="OPT-125M, all 72 layers", block=[(768, 768)] * 4 + [(3072, 768), (768, 3072)], blocks=12, levels=8, moves=0, strip=False),
+    "cfg3": dict(name="OPT-350M, all 144 layers, bias-corrected Hessian", block=[(1024, 1024)] * 4 + [(4096, 1024), (1024, 4096)], blocks=24,
+                 levels=3, moves=0, strip=True),
+    "cfg4": dict(name="BLOOM-560M, all 96 layers", block=[(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)], blocks=24, levels=8,
+                 moves=10, strip=False),
+    "cfg5": dict(name="Llama-FFN 4096x11008 x 32", block=[(4096, 11008)], blocks=32, levels=4, moves=0, strip=False),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--layers", type=int, default=8, help="layers per step")
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default=None, help="a BASELINE.json config's layer stream instead of the headline batch")
+    ap.add_argument("--blocks", type=int, default=0, help="with --config: only this many blocks of the model (0 = all)")
+    ap.add_argument("--layers", type=int, default=8, help="layers per step (headline batch)")
     ap.add_argument("--rows", type=int, default=4096)
     ap.add_argument("--cols", type=int, default=4096)
     ap.add_argument("--levels", type=int, default=8, help="codebook size (8 = 3 bit)")
     ap.add_argument("--moves", type=int, default=0, help="local-search moves")
-    ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic layers cycled through the batch")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic layers cycled through the batch (0 = every layer its own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-layer latency, asymmetric-H and Hessian-accumulation legs")
     ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts (default 3,1)")
     ap.add_argument("--stages", action="store_true", help="also print per-kernel timing table to stderr")
     ap.add_argument("--graphs", action="store_true",
@@ -79,7 +102,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    launch_bound = args.cols <= 1024 and world == 1  # small shapes (see the note on hardware queues at the top)
+    if args.config:
+        wl = dict(WORKLOADS[args.config])
+        if args.blocks:
+            wl["blocks"] = args.blocks
+        shapes = wl["block"] * wl["blocks"]
+        levels, moves, strip = wl["levels"], wl["moves"], wl["strip"]
+    else:
+        shapes = [(args.rows, args.cols)] * args.layers
+        levels, moves, strip = args.levels, args.moves, False
+    L = len(shapes)
+    widest = max(n for _, n in shapes)
+    launch_bound = widest <= 1024 and world == 1  # small shapes (see the note on hardware queues at the top)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if launch_bound else "8")
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     dev_index = local_rank % torch.cuda.device_count()  # (a rehearsal may put several ranks on one GPU)
@@ -99,35 +133,44 @@ def main():
     from sleekit_amd import dist as sdist
 
     dev.lazy_errors = True
-    R, n, L = args.rows, args.cols, args.layers
-    cb = codebook.UniformCodebook(args.levels, -1, 1)
+    cb = codebook.UniformCodebook(levels, -1, 1)
 
-    # ---- inputs, resident in HBM (identical on every rank: integer-hash generator)
+    # ---- inputs, resident in HBM (identical on every rank: integer-hash generator, run on the GPU -- same bytes as
+    #      synth.make_layer on the host, tests/test_gpu_parity.py::test_device_generator_makes_the_same_bytes)
     t_setup = time.time()
-    base = []
-    for i in range(min(args.distinct, L)):
-        lay = synth.make_layer(R, n, 1000 + i, device=device)
-        base.append({k: torch.from_numpy(lay[k]).to(device) for k in ("W", "H", "scale")})
-    layers = [base[i % len(base)] for i in range(L)]
+    distinct = args.distinct if args.distinct > 0 else L
+    made = {}
+    layers = []
+    for i, (R, n) in enumerate(shapes):
+        key = (R, n, i % distinct)
+        if key not in made:
+            lay = synth.make_layer_device(R, n, 1000 + i, device)
+            made[key] = {k: lay[k] for k in ("W", "H", "scale", "mean")}
+        layers.append(made[key])
+    torch.cuda.synchronize()
     host_layer0 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        host_layer0 = {k: base[0][k].cpu().numpy() for k in ("W", "H", "scale")}
+        R0, n0 = shapes[0]
+        rows0 = min(R0, 512) if n0 > 8192 else R0  # (the n^3 factorisation of an 11008-column layer alone is most of a minute)
+        host_layer0 = {k: layers[0][k][:rows0].cpu().numpy() if k != "H" else layers[0][k].cpu().numpy() for k in ("W", "H", "scale", "mean")}
     t_setup = time.time() - t_setup
+    weights_per_step = float(sum(R * n for R, n in shapes))
 
     # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: one loop stream; the batched rounds run on the factor streams)
     streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else ((3, 3) if launch_bound else (3, 1))
-    backend = sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=streams)
+    backend = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=streams)
 
     in_flight = []  # per enqueued step: events at the tail of its loop streams
 
     graphed, gstreams = [], []
     if args.graphs:
-        assert world == 1, "--graphs is a single-GPU mode"
+        assert world == 1 and not strip, "--graphs is a single-GPU mode"
         from sleekit_amd import graphs
 
         gstreams = [torch.cuda.Stream() for _ in range(sum(streams))]
         for i, lay in enumerate(layers):
             # the inputs are resident: the graph reads them in place
+            R, n = shapes[i]
             g = graphs.GraphedLayer(R, n, cb, "diag", 0.01, with_error=True, device=device, inputs=(lay["W"], lay["H"], lay["scale"]))
             with torch.cuda.stream(gstreams[i % len(gstreams)]):
                 g.capture()
@@ -152,15 +195,25 @@ def main():
                 e.synchronize()
         return [dict(row_err=g.row_err) for g in graphed]
 
-    def step():
+    def strip_mean(lay):
+        """a2, remove_input_bias (obq.py:14-25): part of cfg3's path, so inside the step."""
+        n = lay["H"].shape[0]
+        out = torch.empty_like(lay["H"])
+        _lib.check(_lib.lib.slk_hessian_strip_mean(dev.ptr(lay["H"]), dev.ptr(lay["mean"]), n, dev.ptr(out), dev.stream_handle()))
+        return dict(lay, H=out)
+
+    def step(stream_layers=None, be=None):
         if args.graphs:
             return step_graphs()
+        todo = layers if stream_layers is None else stream_layers
+        if strip:
+            todo = [strip_mean(lay) for lay in todo]
         # join=False: consecutive steps are independent batches, so the next step's factorisations start under
         # this step's loops (the fence below waits for everything before the clock stops)
-        shards = sdist.quantize_stream(layers, backend, join=False)
+        shards = sdist.quantize_stream(todo, be or backend, join=False)
         # flow control only: the host enqueues a step several times faster than the GPU runs it, and every step in
         # flight holds its own factors and outputs (2-3 GB); never more than four steps ahead
-        fstreams, _, lstreams = backend.streams()
+        fstreams, _, lstreams = (be or backend).streams()
         if lstreams:
             evs = []
             for st in lstreams + fstreams:
@@ -178,26 +231,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        shards = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(n_steps, n_warm, stream_layers=None):
+        for _ in range(n_warm):
+            step(stream_layers)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            out = step(stream_layers)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    elapsed, shards = timed(args.steps, args.warmup)
     dev.raise_pending()
     peak_hbm = torch.cuda.max_memory_reserved(device)  # after the timed region (at most five steps in flight)
     ms_per_step = 1e3 * elapsed / args.steps
-    weights_per_step = float(L) * R * n
     value = weights_per_step / (elapsed / args.steps) / 1e6
 
     # layer error of the last step (sanity: finite, GPTQ-sized) -- bookkeeping, not timed
-    err0 = float(sdist.layer_error(shards[0]["row_err"], R).item())
+    err0 = float(sdist.layer_error(shards[0]["row_err"], shapes[0][0]).item())
 
     # ---- roofline of the dominant kernel: the SAME K steps once more (same streams, same overlap)
     #      with a pair of HIP events around every launch, recorded on the launch's own stream
@@ -214,52 +270,56 @@ def main():
         _lib.lib.slk_profile_enable(0)
         table = _lib.profile_report()
         _lib.lib.slk_profile_reset()
-        traffic_db = {}
+        traffic_db, traffic_src = {}, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
-            traffic_db = json.load(open(tpath)).get("bytes_per_launch", {})
+            tj = json.load(open(tpath))
+            traffic_db = tj.get("bytes_per_launch", {})
+            traffic_src = f"profiles/pmc_traffic.json ({tj.get('made_by', 'tools/profile_round.sh')}, commit {tj.get('commit', 'unrecorded')}): " \
+                          "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the headline batch, not measured in this run"
         seq = []
         if world == 1 and table:
             # the same kernels with the chip to themselves: one more pass on ONE stream (no kernel shares the CUs)
             _lib.lib.slk_profile_enable(1)
-            sdist.quantize_stream(layers, sdist.HipBackend(cb, "diag", 0.01, args.moves, with_error=True, overlap=False))
+            step(be=sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=False))
             torch.cuda.synchronize()
             _lib.lib.slk_profile_enable(0)
             seq = _lib.profile_report()
             _lib.lib.slk_profile_reset()
+
+        def describe(k, tab):
+            secs = k["total_ms"] * 1e-3
+            kind = KERNEL_DTYPE.get(k["kernel"])
+            t_flops = k["flops"] / PEAK[kind][0] if kind else 0.0
+            t_bytes = k["bytes"] / PEAK["hbm"][0]
+            if kind and t_flops >= t_bytes:
+                achieved, peak, unit, bound = k["flops"] / secs / 1e12, PEAK[kind][0] / 1e12, "TFLOP/s", "mfma"
+                per_launch = k["flops"] / k["launches"]
+            else:
+                achieved, peak, unit, bound = k["bytes"] / secs / 1e9, PEAK["hbm"][0] / 1e9, "GB/s", "hbm"
+                per_launch = k["bytes"] / k["launches"]
+            return {
+                "kernel": k["kernel"], "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 4), "traffic": traffic_db.get(k["kernel"]),
+                "traffic_source": traffic_src if traffic_db.get(k["kernel"]) is not None else None,
+                "launches": k["launches"], "avg_launch_us": round(1e3 * k["total_ms"] / k["launches"], 2),
+                "algorithmic_per_launch": per_launch, "peak_kind": kind or "hbm",
+                "share_of_chip_time": round(k["chip_ms"] / sum(x["chip_ms"] for x in tab), 3),
+                "share_of_kernel_time": round(k["total_ms"] / sum(x["total_ms"] for x in tab), 3),
+            }
+
         if table:
-            # "dominant" = most CHIP time: a launch's duration weighs by the share of the 256 CUs it can
-            # occupy (chip_ms, from the library: min(1, workgroups / 256) x duration), so that the
-            # one-workgroup latency chains of the factorisation, which run beside the wide kernels of
-            # other layers, do not pose as the bottleneck of the step.  The ranking comes from the single-stream
-            # pass when there is one: in the timed region launches of different layers queue for the same CUs
-            # (a window kernel holds a whole CU per workgroup), and a launch's duration then includes its wait,
-            # so the overlapped durations count the same chip time more than once.
+            # "dominant" = most CHIP time in the timed configuration: a launch's duration weighs by the share of the
+            # 256 CUs it can occupy (chip_ms, from the library: min(1, workgroups / 256) x duration), so that the
+            # one-workgroup latency chains of the factorisation, which run beside the wide kernels of other layers,
+            # do not pose as the bottleneck of the step.  (Overlapped durations include queueing for CUs: `alone` below
+            # is the kernel's own rate.)
             for k in table + seq:
                 k.setdefault("chip_ms", k["total_ms"])
             top = max(table, key=lambda k: k["chip_ms"])
-            if seq:
-                lead = max(seq, key=lambda k: k["chip_ms"])["kernel"]
-                top = next((k for k in table if k["kernel"] == lead), top)
-            secs = top["total_ms"] * 1e-3
-            kind = KERNEL_DTYPE.get(top["kernel"])
-            t_flops = top["flops"] / PEAK[kind][0] if kind else 0.0
-            t_bytes = top["bytes"] / PEAK["hbm"][0]
-            if kind and t_flops >= t_bytes:
-                achieved, peak, unit, bound = top["flops"] / secs / 1e12, PEAK[kind][0] / 1e12, "TFLOP/s", "mfma"
-                per_launch = top["flops"] / top["launches"]
-            else:
-                achieved, peak, unit, bound = top["bytes"] / secs / 1e9, PEAK["hbm"][0] / 1e9, "GB/s", "hbm"
-                per_launch = top["bytes"] / top["launches"]
-            roofline = {
-                "kernel": top["kernel"], "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                "frac": round(achieved / peak, 4), "traffic": traffic_db.get(top["kernel"]),
-                "launches": top["launches"], "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
-                "algorithmic_per_launch": per_launch, "peak_kind": kind or "hbm",
-                "share_of_chip_time": round(top["chip_ms"] / sum(k["chip_ms"] for k in table), 3),
-                "share_of_kernel_time": round(top["total_ms"] / sum(k["total_ms"] for k in table), 3),
-                "steps_with_events_ms": round(1e3 * t_prof / args.steps, 3),
-            }
+            roofline = describe(top, table)
+            roofline["steps_with_events_ms"] = round(1e3 * t_prof / args.steps, 3)
+
             # the other kernels of the step, same measurement (share of summed kernel time, roofline fraction)
             def frac_of(k):
                 kd = KERNEL_DTYPE.get(k["kernel"])
@@ -278,12 +338,15 @@ def main():
             # kernel's own rate.
             alone = next((k for k in seq if k["kernel"] == roofline["kernel"]), None)
             if alone:
-                a_secs = alone["total_ms"] * 1e-3
-                a_ach = (alone["flops"] / a_secs / 1e12) if roofline["bound"] == "mfma" else (alone["bytes"] / a_secs / 1e9)
-                roofline["alone"] = {"avg_launch_us": round(1e3 * alone["total_ms"] / alone["launches"], 2),
-                                     "achieved": round(a_ach, 3), "frac": round(a_ach / roofline["peak"], 4),
-                                     "share_of_chip_time": round(alone["chip_ms"] / sum(k["chip_ms"] for k in seq), 3),
+                d = describe(alone, seq)
+                roofline["alone"] = {"avg_launch_us": d["avg_launch_us"], "achieved": d["achieved"], "frac": d["frac"],
+                                     "share_of_chip_time": d["share_of_chip_time"],
                                      "note": "single-stream pass after the timed region: no other kernel shares the chip"}
+            lead = max(seq, key=lambda k: k["chip_ms"])
+            if lead["kernel"] != roofline["kernel"]:
+                d = describe(lead, seq)
+                roofline["single_stream_leader"] = {k: d[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                                      "avg_launch_us", "algorithmic_per_launch", "share_of_chip_time")}
         if args.stages and rank == 0 and world == 1 and table:
             tot = sum(k["total_ms"] for k in seq)
             print(f"  single-stream pass: {tot:.3f} ms of kernels for {L} layers", file=sys.stderr)
@@ -294,9 +357,45 @@ def main():
                     file=sys.stderr,
                 )
 
+    extras = rank == 0 and world == 1 and not args.no_extras and not args.graphs
+    # ---- one isolated layer, start to finish ("report the single-layer number separately")
+    latency = None
+    if extras:
+        lat = []
+        for i in range(6):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            one = [layers[i % L]]
+            sdist.quantize_stream([strip_mean(one[0])] if strip else one, backend, join=True)
+            torch.cuda.synchronize()
+            lat.append(1e3 * (time.perf_counter() - t1))
+        latency = {"ms": round(float(np.median(lat[1:])), 3), "shape": list(shapes[0]) if len(set(shapes)) == 1 else [list(shapes[i % L]) for i in range(1, 6)],
+                   "note": "median of 5 after one warm-up: a single layer alone on the GPU, host call to synchronize"}
+
+    # ---- the same workload on Hessians that are NOT bit-symmetric (made by a library GEMM, like the experiments' dumps
+    #      of torch `inp @ inp.t()`): the layer error cannot halve its work then
+    asym = None
+    if extras and not args.config:
+        n = args.cols
+        alt = {}
+        for i, lay in enumerate(layers):
+            if id(lay) not in alt:
+                X = torch.randn(2 * n, n, device=device) * (0.5 + 2.0 * torch.rand(n, device=device))
+                X[:, :8] *= 8.0
+                Ha = (X.T @ X) / float(2 * n)
+                alt[id(lay)] = dict(lay, H=Ha)
+        alt_layers = [alt[id(lay)] for lay in layers]
+        symmetric = all(bool(torch.equal(a["H"], a["H"].T)) for a in alt.values())
+        el, _ = timed(args.steps, 1, alt_layers)
+        dev.raise_pending()
+        asym = {"value": round(weights_per_step / (el / args.steps) / 1e6, 2), "unit": "Mweights/s", "ms_per_layer": round(1e3 * el / args.steps / L, 3),
+                "H": "torch X.T @ X / T in float32 (library GEMM)", "bitwise_symmetric": symmetric}
+        del alt, alt_layers
+
     # ---- a1, Hessian accumulation, timed as its own stage: 2048-token batches into an n x n Hessian
     hess = None
-    if rank == 0 and world == 1:
+    if extras:
+        n = widest
         Hacc = torch.zeros((n, n), dtype=torch.float32, device=device)
         macc = torch.zeros(n, dtype=torch.float32, device=device)
         X = torch.randn(2048, n, device=device)
@@ -313,7 +412,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 4
         flops = 2048.0 * n * (n + 1)
-        hess = {"tokens_per_batch": 2048, "ms_per_batch": round(ms, 3), "achieved_tflops": round(flops / ms / 1e9, 2),
+        hess = {"features": n, "tokens_per_batch": 2048, "ms_per_batch": round(ms, 3), "achieved_tflops": round(flops / ms / 1e9, 2),
                 "peak_tflops": PEAK["mfma_f32"][0] / 1e12, "frac": round(flops / ms / 1e9 / (PEAK["mfma_f32"][0] / 1e12), 4),
                 "algorithmic_flops": "T n (n + 1): one triangle, float32 by definition; executed as six bfloat16 products each when n % 128 == 0"}
 
@@ -322,36 +421,47 @@ def main():
     if host_layer0 is not None:
         from oracle import grid, obq_ref, scaling_ref
 
-        g = grid.UniformGrid(args.levels, -1, 1)
+        g = grid.UniformGrid(levels, -1, 1)
         small = synth.make_layer(512, 512, 999)
         scaling_ref.quantize_scaled(small["W"], small["scale"], g, small["H"])  # LAPACK/BLAS warm-up
         t1 = time.perf_counter()
-        out = scaling_ref.quantize_scaled(host_layer0["W"], host_layer0["scale"], g, host_layer0["H"], "diag", 0.01, args.moves)
-        e_cpu = float(obq_ref.mean_error(host_layer0["W"], out, host_layer0["H"]))
+        H0 = obq_ref.strip_input_mean(host_layer0["H"], host_layer0["mean"]) if strip else host_layer0["H"]
+        out = scaling_ref.quantize_scaled(host_layer0["W"], host_layer0["scale"], g, H0, "diag", 0.01, moves)
+        e_cpu = float(obq_ref.mean_error(host_layer0["W"], out, H0))
         t_cpu = time.perf_counter() - t1
+        R0, n0 = host_layer0["W"].shape
         cpu = {
-            "value": round(R * n / t_cpu / 1e6, 3), "unit": "Mweights/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"1 layer {R}x{n} (same inputs as GPU layer 0), quantize_with_scaling + quantization_error, "
-                      f"NumPy {np.__version__} OpenBLAS threads=all, after a 512x512 warm-up; {t_cpu:.2f} s",
-            "layer_error": e_cpu, "gpu_layer_error": err0,
+            "value": round(R0 * n0 / t_cpu / 1e6, 3), "unit": "Mweights/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 layer {R0}x{n0} (inputs of GPU layer 0{'' if R0 == shapes[0][0] else ', first ' + str(R0) + ' rows'}), quantize_with_scaling + "
+                      f"quantization_error, {levels} levels, moves={moves}, NumPy {np.__version__} OpenBLAS threads=all, after a 512x512 warm-up; {t_cpu:.2f} s",
+            "layer_error": e_cpu, "gpu_layer_error": err0 if R0 == shapes[0][0] else None,
         }
 
     if rank == 0:
+        if args.config:
+            wl = WORKLOADS[args.config]
+            metric = f"Mweights/sec quantized ({wl['name']}, {np.log2(levels):.3g}-bit)"
+            workload = (f"{args.config}: {wl['name']} in model order, {L} layers, {levels}-level uniform codebook, act_order=diag, damp=0.01, "
+                        f"local-search moves={moves}, {'H - m m^T, ' if strip else ''}layer error included")
+        else:
+            metric = "Mweights/sec quantized (GPTQ 3-bit, 4096x4096 layer)"
+            workload = (f"{L} layers {args.rows}x{args.cols}, {levels}-level uniform codebook (GPTQ {np.log2(levels):g}-bit), "
+                        f"act_order=diag, damp=0.01, local-search moves={moves}, layer error included")
         line = {
-            "metric": "Mweights/sec quantized (GPTQ 3-bit, 4096x4096 layer)", "value": round(value, 2), "unit": "Mweights/s",
+            "metric": metric, "value": round(value, 2), "unit": "Mweights/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{L} layers {R}x{n}, {args.levels}-level uniform codebook (GPTQ {np.log2(args.levels):g}-bit), "
-                            f"act_order=diag, damp=0.01, local-search moves={args.moves}, layer error included",
-                "layers_per_step": L, "rows": R, "cols": n, "row_sharding": f"{world} ranks x {R // world} rows",
+                "workload": workload, "layers_per_step": L, "distinct_inputs": len(made),
+                "shapes": sorted({f"{R}x{n}" for R, n in shapes}), "row_sharding": f"{world} ranks",
                 "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(t_setup, 1),
                 "peak_hbm_gb": round(peak_hbm / 2**30, 2),
                 "streams": {"factor": streams[0], "loop": streams[1]}, "hip_graphs": bool(args.graphs),
                 "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
             },
-            "roofline": roofline, "cpu_baseline": cpu, "layer_error": err0, "hessian_accumulate": hess,
+            "roofline": roofline, "cpu_baseline": cpu, "layer_error": err0, "latency_ms_single_layer": latency,
+            "asymmetric_H": asym, "hessian_accumulate": hess,
         }
         print(json.dumps(line))
     if world > 1:

@@ -25,7 +25,21 @@ import torch.distributed as dist
 always_exchange = False
 
 
+# Measurement hook (tools/micro_rank_of_n.py): (rank, size) makes this process behave as ONE rank of a larger job on a
+# single GPU -- same rounds, roots, streams and kernels -- with the all-gather replaced by a local hand-over of this
+# rank's own payload in every slot (the results are meaningless, the work is that of the real rank).
+rehearse = None
+_rehearsal_payloads = {}
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
 def world():
+    if rehearse is not None:
+        return rehearse
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
@@ -38,8 +52,39 @@ def row_range(R, rank, size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def factor_root(layer_index, size):
-    return layer_index % size
+def factor_root(position, size):
+    """Root of the layer at `position` of the processing order (plan_rounds): positions go round the ranks."""
+    return position % size
+
+
+def plan_rounds(layers, size, bucket=True):
+    """Rounds of at most `size` layers, each of ONE shape, and every layer's factor root.
+
+    A model's layers come in an order that mixes shapes (an OPT / BLOOM block is {d x d ..., 4d x d, d x 4d};
+    reference: experiments/compare.py:37-53 walks one directory per layer), but they are independent
+    (compare.py:50-131), so the stream is bucketed by (rows, columns, scaled?) and each bucket cut into rounds: the
+    row shards of a round's layers then go through the kernels as one batch (HipBackend.run_round).  Roots follow
+    the position in this processing order, so a bucket's partial last round does not leave the same ranks idle
+    every time.  Returns (rounds, root): rounds = lists of layer indices, root[l] = the rank that factors layer l.
+    """
+    n_layers = len(layers)
+    if size <= 1 or not bucket:
+        groups = [list(range(n_layers))]
+    else:
+        by_shape = {}
+        for l, lay in enumerate(layers):
+            key = (tuple(lay["W"].shape), tuple(lay["H"].shape), lay.get("scale") is not None)
+            by_shape.setdefault(key, []).append(l)
+        groups = list(by_shape.values())  # in order of first appearance
+    rounds, root, position = [], [None] * n_layers, 0
+    for members in groups:
+        for i in range(0, len(members), max(size, 1)):
+            chunk = members[i:i + max(size, 1)]
+            for l in chunk:
+                root[l] = factor_root(position, max(size, 1))
+                position += 1
+            rounds.append(chunk)
+    return rounds, root
 
 
 class HipBackend:
@@ -131,7 +176,7 @@ class HipBackend:
     min_batch = 2  # (tests set 1 to send single-layer rounds through run_round as well)
 
     def can_batch(self, round_layers, lo, hi):
-        if len(round_layers) < self.min_batch or len(round_layers) > 64 or (hi - lo) % 128 != 0 or hi == lo:
+        if len(round_layers) < self.min_batch or len(round_layers) > 64 or hi == lo:
             return False
         first = round_layers[0]
         scaled = first.get("scale") is not None
@@ -148,6 +193,8 @@ class HipBackend:
         eng = self.engine
         B, n = len(round_layers), round_layers[0]["H"].shape[0]
         device = round_layers[0]["W"].device
+        rows = hi - lo
+        Rp = (rows + 127) // 128 * 128  # the batch entry points want whole 128-row tiles per layer (96 rows at 768 / 8)
         # the stacked factors live in a buffer per stream, zeroed once: only the upper triangles are rewritten each round
         # (use on one stream is ordered; rounds on other streams have buffers of their own)
         if not hasattr(self, "_ustacks"):
@@ -161,19 +208,29 @@ class HipBackend:
         for b, payload in enumerate(payloads):
             _lib.check(_lib.lib.slk_factor_unpack_upper(dev.ptr(payload), n, U[b].data_ptr(), order[b].data_ptr(),
                                                         info[b:b + 1].data_ptr(), dev.stream_handle()))
-        W = torch.stack([lay["W"][lo:hi] for lay in round_layers])
-        sc = torch.stack([lay["scale"][lo:hi] for lay in round_layers]) if round_layers[0].get("scale") is not None else None
+        scaled = round_layers[0].get("scale") is not None
+        if Rp == rows:
+            W = torch.stack([lay["W"][lo:hi] for lay in round_layers])
+            sc = torch.stack([lay["scale"][lo:hi] for lay in round_layers]) if scaled else None
+        else:
+            # ragged shard: every layer's rows padded to whole tiles (zero weights, unit scale); rows never interact,
+            # so the padding rows are wasted work and nothing else -- they are cut off below
+            W = torch.zeros((B, Rp, n), dtype=torch.float32, device=device)
+            sc = torch.ones((B, Rp), dtype=torch.float32, device=device) if scaled else None
+            for b, lay in enumerate(round_layers):
+                W[b, :rows].copy_(lay["W"][lo:hi])
+                if scaled:
+                    sc[b, :rows].copy_(lay["scale"][lo:hi])
         cb = eng.require_uniform(self.quantizer)
         if self.moves > 0:
             # local search works in the scaled domain (engine.quantize_layer): scaled copy in, one search per layer
             # (a workgroup per row each: already wide), de-scale on the way out
-            R = hi - lo
-            Ws = eng.rows_divide(W.view(B * R, n), sc.reshape(-1)).view(B, R, n) if sc is not None else W
+            Ws = eng.rows_divide(W.view(B * Rp, n), sc.reshape(-1)).view(B, Rp, n) if sc is not None else W
             Q, idx = eng.run_loop_batch(Ws, None, order, U, cb, 32, 8)
             for b, lay in enumerate(round_layers):
-                eng.local_search(Ws[b], Q[b], lay["H"], cb, self.moves, idx[b])
+                eng.local_search(Ws[b, :rows], Q[b, :rows], lay["H"], cb, self.moves, idx[b, :rows])
             if sc is not None:
-                Q = eng.rows_divide(Q.view(B * R, n), sc.reshape(-1), invert=True).view(B, R, n)
+                Q = eng.rows_divide(Q.view(B * Rp, n), sc.reshape(-1), invert=True).view(B, Rp, n)
         else:
             Q, idx = eng.run_loop_batch(W, sc, order, U, cb, 32, 8, unscale=sc is not None)
         err = None
@@ -182,8 +239,8 @@ class HipBackend:
             # (every rank runs the same backend settings, so with_error here means the roots packed real verdicts)
             known = torch.stack([p[mark] for p in payloads]).to(torch.int32)
             err = eng.row_errors_batch(W, Q, [lay["H"] for lay in round_layers], known)
-        return [dict(Q=Q[b], idx=idx[b], row_err=None if err is None else err[b], rows=(lo, hi), info=info[b:b + 1])
-                for b in range(B)]
+        return [dict(Q=Q[b, :rows], idx=idx[b, :rows], row_err=None if err is None else err[b, :rows], rows=(lo, hi),
+                     info=info[b:b + 1]) for b in range(B)]
 
 
 class _NullCtx:
@@ -196,6 +253,8 @@ class _NullCtx:
 
 def _all_gather_words(payload, size):
     """All-gather equal-sized int64 buffers; returns (list of per-rank views, async work)."""
+    if rehearse is not None:
+        return [payload] * size, _Done()
     if dist.get_backend() == "nccl":
         out = torch.empty(size * payload.numel(), dtype=payload.dtype, device=payload.device)
         work = dist.all_gather_into_tensor(out, payload, async_op=True)
@@ -211,9 +270,10 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
     Every rank holds every layer's inputs (W, H are inputs of the path and resident before
     it starts); only the factor travels.
 
-    Layers are taken in ROUNDS of G (= world size): in round g rank r factors layer g G + r, then
-    ONE collective per round exchanges the packed factors (status, order, upper triangle of U:
-    n (n + 1) / 2 + n + 1 words per layer).  It is an all-gather -- G simultaneous one-to-all
+    Layers are taken in ROUNDS of at most G (= world size) layers of ONE shape (plan_rounds: the stream is
+    bucketed by shape first, since a model's layer order mixes shapes and the layers are independent); the
+    ranks factor one layer of the round each, then ONE collective per round exchanges the packed factors
+    (status, order, upper triangle of U: n (n + 1) / 2 + n + 1 words per layer).  It is an all-gather -- G simultaneous one-to-all
     broadcasts -- because xGMI is a point-to-point mesh: every rank then receives over all of its
     7 links at once, where G separate ring broadcasts would each crawl through one link per hop.
 
@@ -230,22 +290,24 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
     """
     rank, size = world()
     n_layers = len(layers)
-    n_rounds = (n_layers + size - 1) // size
-    factors = [None] * n_layers
-    ready = [None] * n_layers
     fstreams, cstream, lstreams = backend.streams() if hasattr(backend, "streams") else (None, None, None)
     side = fstreams is not None
     here = torch.cuda.current_stream() if side else None
     exchange = size > 1 or always_exchange
+    # rounds of one shape each; root[l] = the rank that factors layer l (plan_rounds)
+    rounds, root = plan_rounds(layers, size, bucket=exchange and getattr(backend, "bucket_by_shape", True))
+    n_rounds = len(rounds)
+    factors = [None] * n_layers
+    ready = [None] * n_layers
 
     def on(stream):
         return torch.cuda.stream(stream) if stream is not None else _NullCtx()
 
-    # 1. every rank factors the layers it is the root of (concurrently across ranks); the
+    # 1. every rank factors the layers it is the root of (concurrently across ranks), in processing order; the
     #    factorisations are latency-bound chains, so consecutive ones alternate between streams
     #    (the rotation carries on from the previous call: with one layer per rank and call -- a round of G
     #    layers on G ranks -- consecutive calls would otherwise queue on the same stream, one chain behind the other)
-    mine = list(range(rank, n_layers, size))
+    mine = [l for members in rounds for l in members if root[l] == rank]
     first = getattr(backend, "_factor_rotation", 0) if side else 0
     if side:
         backend._factor_rotation = (first + len(mine)) % len(fstreams)
@@ -267,35 +329,41 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
         if cstream is not None:
             cstream.wait_stream(here)
         with on(cstream):
-            for g in range(n_rounds):
-                l = g * size + rank
-                # equal-sized contributions: pad to the widest layer of the round
-                words = max(backend.payload_words(layers[j]["H"].shape[0])
-                            for j in range(g * size, min((g + 1) * size, n_layers)))
-                if l < n_layers:
+            for g, members in enumerate(rounds):
+                own = [l for l in members if root[l] == rank]  # at most one: a round has at most `size` layers
+                # equal-sized contributions: a round's layers share one shape (padded to the widest otherwise)
+                words = max(backend.payload_words(layers[j]["H"].shape[0]) for j in members)
+                if own:
+                    l = own[0]
                     if ready[l] is not None:
                         cstream.wait_event(ready[l])
                     payload = backend.pack(factors[l], words)
                     if side:
                         for t in factors[l]:
                             t.record_stream(cstream)  # made on a factor stream, read here
-                else:  # no layer for this rank in the last round: contribute a blank
+                elif rehearse is not None:
+                    # rehearsal: a real factor of the right shape must stand in for the peers' (a blank one is not a
+                    # permutation + triangle the kernels can run on); made once per shape, outside what is measured
+                    n_ = layers[members[0]]["H"].shape[0]
+                    if (n_, words) not in _rehearsal_payloads:
+                        _rehearsal_payloads[(n_, words)] = backend.pack(backend.factorize(layers[members[0]]), words)
+                    payload = _rehearsal_payloads[(n_, words)]
+                else:  # no layer of this round is this rank's: contribute a blank
                     dev_ = comm_device if comm_device is not None else layers[0]["H"].device
                     payload = backend.alloc_payload(words, dev_).zero_()
                 gathered[g] = _all_gather_words(payload, size)
                 keep.append(payload)
-    # 3. every rank runs its rows of every layer as the factors land, round by round.  A round whose layers
-    #    share one shape goes through the kernels as ONE batch when the backend can do that (run_round): the
-    #    shards are R / G rows each, too few to fill the chip alone.  Otherwise layer by layer, consecutive
-    #    ones on alternating streams (their leaf chains are latency-bound).
-    out = []
+    # 3. every rank runs its rows of every layer as the factors land, round by round.  A round goes through the
+    #    kernels as ONE batch when the backend can do that (run_round): the shards are R / G rows each, too few to
+    #    fill the chip alone.  Otherwise layer by layer, consecutive ones on alternating streams (their leaf chains
+    #    are latency-bound).
+    out = [None] * n_layers
     if side:
         for st in lstreams:
             st.wait_stream(here)
     # (batched rounds rotate over the loop streams across calls, like the factorisations above)
     batched_rounds = getattr(backend, "_loop_rotation", 0) if side else 0
-    for g in range(n_rounds):
-        members = list(range(g * size, min((g + 1) * size, n_layers)))
+    for g, members in enumerate(rounds):
         lo, hi = row_range(layers[members[0]]["W"].shape[0], rank, size)
         if exchange and hasattr(backend, "run_round") and backend.can_batch([layers[l] for l in members], lo, hi):
             ls = lstreams[batched_rounds % len(lstreams)] if side else None
@@ -314,11 +382,12 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
             with on(ls):
                 parts, work = gathered[g]
                 work.wait()  # orders the stream behind the transfer; no host block on GPU
-                shards = backend.run_round([layers[l] for l in members], lo, hi, [parts[l % size] for l in members])
+                shards = backend.run_round([layers[l] for l in members], lo, hi, [parts[root[l]] for l in members])
                 if side:
                     for t in parts:
                         t.record_stream(ls)
-            out.extend(shards)
+            for l, shard in zip(members, shards):
+                out[l] = shard
             continue
         for l in members:
             layer = layers[l]
@@ -328,7 +397,7 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
                     parts, work = gathered[g]
                     work.wait()
                     if factors[l] is None or always_exchange:
-                        factors[l] = backend.unpack(parts[l % size], layer["H"].shape[0])
+                        factors[l] = backend.unpack(parts[root[l]], layer["H"].shape[0])
                 elif ready[l] is not None:
                     ls.wait_event(ready[l])
                 lo, hi = row_range(layer["W"].shape[0], rank, size)
@@ -340,7 +409,7 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
                         for t in gathered[g][0]:
                             t.record_stream(ls)
             shard["info"] = factors[l][2]
-            out.append(shard)
+            out[l] = shard
     if side:
         if join:
             for st in lstreams + fstreams:  # (batched rounds run on factor streams)

@@ -143,3 +143,66 @@ def make_layer(R, n, seed, T=None, dead=(), device=None):
     W = make_weights(R, n, seed)
     H, mean, T = make_hessian(n, seed, T=T, dead=dead, device=device)
     return dict(W=W, H=H, mean=mean, scale=make_scale(W), T=T, seed=seed)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The same generator on the GPU (torch): identical bytes -- integer hashing in wrapping int64 arithmetic,
+# IEEE float64 +, -, *, / element by element (no fused multiply-add: every product is a tensor of its own),
+# exact integer float64 matrix products -- so that benchmarks can set up whole models in seconds
+# (tests/test_gpu_parity.py::test_device_generator_makes_the_same_bytes holds it to the host generator).
+def _t_splitmix64(x):
+    import torch  # noqa: F401
+
+    def lsr(v, k):  # logical shift right of an int64 tensor
+        return (v >> k) & ((1 << (64 - k)) - 1)
+
+    z = x + (-7046029254386353131)            # 0x9E3779B97F4A7C15 as int64
+    z = (z ^ lsr(z, 30)) * (-4658895280553007687)  # 0xBF58476D1CE4E5B9
+    z = (z ^ lsr(z, 27)) * (-7723592293110705685)  # 0x94D049BB133111EB
+    return z ^ lsr(z, 31)
+
+
+def _t_hash_grid(seed, stream, rows, cols, device, row0=0):
+    import torch
+
+    key = int(np.array([_key(seed, stream)], dtype=np.uint64).view(np.int64)[0])
+    i = (torch.arange(row0, row0 + rows, dtype=torch.int64, device=device) << 32)[:, None]
+    j = torch.arange(cols, dtype=torch.int64, device=device)[None, :]
+    return _t_splitmix64((i | j) ^ key)
+
+
+def _t_normal_grid(seed, stream, rows, cols, device, row0=0):
+    import torch
+
+    u = _t_hash_grid(seed, stream, rows, cols, device, row0)
+    s = (u & 0xFFFF) + ((u >> 16) & 0xFFFF) + ((u >> 32) & 0xFFFF) + ((u >> 48) & 0xFFFF)
+    return (s.to(torch.float64) - 131070.0) / 37837.2
+
+
+def make_layer_device(R, n, seed, device, T=None, chunk=4096, keep=("W", "H", "mean", "scale")):
+    """make_layer on the GPU: dict of device tensors W, H, mean, scale (+ T, seed), bit-identical to make_layer."""
+    import torch
+
+    T = 2 * n if T is None else T
+    W = (0.02 * _t_normal_grid(seed, 1, R, n, device)).to(torch.float32)
+    gain, load, offset = (torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in _channel_params(n, seed))
+    acc = torch.zeros((n, n), dtype=torch.float64, device=device)
+    col = torch.zeros(n, dtype=torch.float64, device=device)
+    for t0 in range(0, T, chunk):
+        rows = min(chunk, T - t0)
+        x = _t_normal_grid(seed, 6, rows, n, device, row0=t0) * gain[None, :]
+        f = _t_normal_grid(seed, 7, rows, 8, device, row0=t0)
+        for k in range(8):
+            x = x + f[:, k:k + 1] * load[None, :, k]
+        x = x + offset[None, :]
+        xi = torch.round(x * _FIX)  # half-to-even, like np.rint; integers
+        acc += xi.T @ xi
+        col += xi.sum(dim=0)
+    assert float(acc.abs().max()) < 2.0**53
+    H = (acc / (_FIX * _FIX * T)).to(torch.float32)
+    mean = (col / (_FIX * T)).to(torch.float32)
+    scale = torch.clamp(W.abs().amax(dim=1) / np.float32(1.0) * np.float32(0.6), min=1.0e-16).to(torch.float32)
+    out = dict(W=W, H=H, mean=mean, scale=scale)
+    out = {k: v for k, v in out.items() if k in keep}
+    out.update(T=T, seed=seed)
+    return out

@@ -2,7 +2,8 @@
 
 Both ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one GPU): the row shards of a round's
 layers go through the batched loop (HipBackend.run_round; also with local-search moves) and must equal, bit for bit, the rows of the
-unsharded single-GPU result; a ragged layer and a lone last layer take the layer-by-layer route in the same call.
+unsharded single-GPU result.  The stream is in MODEL order (shapes alternate): sleekit_amd.dist buckets it by shape, pads the ragged
+shards to whole tiles, and only the lone last layer takes the layer-by-layer route.
 """
 
 import os
@@ -24,7 +25,8 @@ def main():
     dist.init_process_group("gloo")
     rank, size = dist.get_rank(), dist.get_world_size()
     cb = codebook.UniformCodebook(8, -1, 1)
-    shapes = [(256, 512), (256, 512), (512, 1024), (512, 1024), (100, 192), (64, 192), (256, 320)]
+    # a model-order stream: shapes alternate like the layers of a transformer block; (100, 192) shards are ragged (50 rows)
+    shapes = [(256, 512), (512, 1024), (100, 192), (256, 512), (512, 1024), (100, 192), (256, 320)]
     layers = []
     for i, (R, n) in enumerate(shapes):
         lay = synth.make_layer(R, n, 300 + i)
@@ -48,7 +50,8 @@ def main():
             assert np.array_equal(sh["idx"].cpu().numpy(), res.idx[lo:hi].cpu().numpy())
             np.testing.assert_allclose(sh["row_err"].cpu().numpy(), err[lo:hi].cpu().numpy(), rtol=1e-5)
             assert int(sh["info"].item()) == 0
-    assert calls["round"] == 3 * 2 and calls["rows"] == 3 * 3, calls  # rounds (0,1), (2,3) batched; (4,5) ragged, (6) alone
+    # bucketed by shape: rounds (0, 3), (1, 4) and the ragged (2, 5) -- padded to whole tiles -- batched; (6) alone
+    assert calls["round"] == 3 * 3 and calls["rows"] == 3 * 1, calls
     dist.barrier()
     dist.destroy_process_group()
     print(f"DIST_ROUND_OK rank {rank}", flush=True)

@@ -118,6 +118,30 @@ def _worker_batched(rank, size, port, q):
         dist.destroy_process_group()
 
 
+def make_model_order_layers():
+    """A miniature of BASELINE's cfg2 stream: three 'blocks' of {4 x (d x d), 4d x d, d x 4d} in model order."""
+    g = torch.Generator().manual_seed(23)
+    layers = []
+    for block in range(3):
+        for R, n in [(6, 6)] * 4 + [(12, 6), (6, 12)]:
+            A = torch.randn(n, n, generator=g)
+            layers.append(dict(id=torch.tensor(len(layers)), W=torch.randn(R, n, generator=g), H=(A @ A.T).float()))
+    return layers
+
+
+def _worker_model_order(rank, size, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        layers = make_model_order_layers()
+        be = FakeBatchBackend()
+        shards = sdist.quantize_stream(layers, be)
+        q.put((rank, be.rounds, be.factored, [(s["rows"], s["Q"].numpy().copy(), int(s["info"].item())) for s in shards]))
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -181,5 +205,54 @@ def test_batched_rounds_over_gloo_world2():
         R = layer["W"].shape[0]
         (lo0, hi0), q0, i0 = got[0][2][l]
         (lo1, hi1), q1, i1 = got[1][2][l]
+        assert (lo0, hi1) == (0, R) and hi0 == lo1 and i0 == 0 and i1 == 0
+        assert torch.equal(torch.cat([torch.from_numpy(q0), torch.from_numpy(q1)]), single[l]["Q"])
+
+
+def test_plan_rounds_buckets_a_model_order_stream():
+    """BASELINE cfg2-cfg4 streams at 8 ranks: every round is of one shape, at most 8 layers, and the roots are balanced."""
+    def stream(block, blocks):
+        return [dict(W=torch.empty(R, n, device="meta"), H=torch.empty(n, n, device="meta")) for _ in range(blocks) for R, n in block]
+
+    cfg2 = stream([(768, 768)] * 4 + [(3072, 768), (768, 3072)], 12)
+    cfg4 = stream([(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)], 24)
+    for layers, n_rounds in ((cfg2, 6 + 2 + 2), (cfg4, 12)):
+        rounds, root = sdist.plan_rounds(layers, 8)
+        assert len(rounds) == n_rounds and sorted(l for r in rounds for l in r) == list(range(len(layers)))
+        for members in rounds:
+            assert len(members) <= 8 and len({tuple(layers[l]["W"].shape) for l in members}) == 1
+            assert len({root[l] for l in members}) == len(members)  # one layer per rank and round
+        per_rank = [sum(1 for x in root if x == r) for r in range(8)]
+        assert max(per_rank) - min(per_rank) <= 1, per_rank
+    # a single rank keeps the stream's own order, one layer per round
+    rounds, root = sdist.plan_rounds(cfg2[:7], 1)
+    assert rounds == [[i] for i in range(7)] and root == [0] * 7
+
+
+@pytest.mark.timeout(120)
+def test_model_order_stream_over_gloo_world2():
+    """A stream in MODEL order (shapes alternate) on two ranks: bucketed into rounds of one shape, every round batched
+    through run_round, roots balanced, shards == rows of the unsharded result."""
+    single = sdist.quantize_stream(make_model_order_layers(), FakeBackend())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_model_order, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=90) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    square = [l for l in range(18) if l % 6 < 4]
+    want_rounds = [square[i:i + 2] for i in range(0, 12, 2)] + [[4, 10], [16], [5, 11], [17]]
+    for rank in range(2):
+        assert got[rank][1] == [r for r in want_rounds if len(r) == 2]  # the lone leftovers go layer by layer
+        assert len(got[rank][2]) == 9  # 18 factorisations, 9 each
+    assert sorted(got[0][2] + got[1][2]) == list(range(18))
+    for l, layer in enumerate(make_model_order_layers()):
+        R = layer["W"].shape[0]
+        (lo0, hi0), q0, i0 = got[0][3][l]
+        (lo1, hi1), q1, i1 = got[1][3][l]
         assert (lo0, hi1) == (0, R) and hi0 == lo1 and i0 == 0 and i1 == 0
         assert torch.equal(torch.cat([torch.from_numpy(q0), torch.from_numpy(q1)]), single[l]["Q"])

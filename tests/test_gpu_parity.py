@@ -150,6 +150,16 @@ def test_diag_mean_follows_numpy_order(amd, n):
     assert np.float32(out.item()) == npsum.mean_f32(d) == d.mean()
 
 
+def test_device_generator_makes_the_same_bytes():
+    """bench.py sets its layers up with synth.make_layer_device (integer hashing and exact float64 arithmetic in
+    torch on the GPU): the bytes must be those of the host generator the fixtures were made from."""
+    for R, n, seed in ((64, 96, 2001), (96, 172, 2003), (256, 768, 2010), (40, 1100, 77)):
+        host = layer(R, n, seed)
+        got = synth.make_layer_device(R, n, seed, torch.device("cuda"), chunk=512)
+        for k in ("W", "H", "mean", "scale"):
+            assert np.array_equal(got[k].cpu().numpy(), host[k]), (R, n, k)
+
+
 # --------------------------------------------------------------------------- order + factor
 @pytest.mark.parametrize("R,n,seed", [(8, 16, 2000), (64, 96, 2001), (96, 172, 2003), (256, 768, 2010), (8, 1100, 2040)])
 def test_order_and_factor(amd, R, n, seed):

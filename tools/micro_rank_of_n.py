@@ -1,11 +1,13 @@
-"""What ONE rank of an N-GPU run does per step, timed on this one GPU (no transfer: the all-gather is
-replaced by handing the packed payload over locally).
+"""What ONE rank of an N-GPU run does per step, timed on this one GPU through the real scheduling code
+(sleekit_amd.dist.quantize_stream with dist.rehearse = (0, N): same rounds, roots, streams and kernels; the
+all-gather is replaced by handing this rank's own packed payload over locally).
 
-    python tools/micro_rank_of_n.py [N ...]
+    python tools/micro_rank_of_n.py [N ...] [--config cfg2|cfg3|cfg4|cfg5] [--blocks B] [--kernels]
 
-Per step of 8 layers 4096 x 4096: 8 / N factorisations + packs, 8 (N - 1) / N unpacks, 8 loops + errors of
-4096 / N rows.  Prints ms per step and the whole-job rate N such ranks would reach if the exchange hid
-completely behind the loops (an upper bound for bench.py --gpus N).
+Default workload: bench.py's headline batch (8 layers 4096 x 4096).  Prints ms per step on the rank, how many
+rounds went through the batched route (HipBackend.run_round) and how many layers layer by layer, and the whole-job
+rate N such ranks would reach if the exchange hid completely behind the loops -- an upper bound for
+`bench.py --gpus N`, NOT a measurement of it.
 """
 
 import os
@@ -18,103 +20,64 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
+import bench  # noqa: E402  (WORKLOADS)
 from sleekit_amd import _device as dev  # noqa: E402
-from sleekit_amd import codebook, synth  # noqa: E402
+from sleekit_amd import _lib, codebook, synth  # noqa: E402
 from sleekit_amd import dist as sdist  # noqa: E402
 
 
 def main():
-    Ns = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 2, 4, 8]
+    argv = sys.argv[1:]
+    Ns = [int(a) for a in argv if a.isdigit()] or [1, 2, 4, 8]
+    cfg = argv[argv.index("--config") + 1] if "--config" in argv else None
+    blocks = int(argv[argv.index("--blocks") + 1]) if "--blocks" in argv else 0
+    if "--blocks" in argv:
+        Ns = [x for x in Ns if x != blocks] or Ns
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     dev.lazy_errors = True
-    R = n = 4096
-    L = 8
-    cb = codebook.UniformCodebook(8, -1, 1)
-    base = []
-    for i in range(2):
-        lay = synth.make_layer(R, n, 1000 + i, device=device)
-        base.append({k: torch.from_numpy(lay[k]).to(device) for k in ("W", "H", "scale")})
-    layers = [base[i % 2] for i in range(L)]
+    if cfg:
+        wl = bench.WORKLOADS[cfg]
+        shapes = wl["block"] * (blocks or wl["blocks"])
+        levels, moves, strip = wl["levels"], wl["moves"], wl["strip"]
+    else:
+        shapes, levels, moves, strip = [(4096, 4096)] * 8, 8, 0, False
+    cb = codebook.UniformCodebook(levels, -1, 1)
+    layers = []
+    for i, (R, n) in enumerate(shapes):
+        lay = synth.make_layer_device(R, n, 1000 + i, device)
+        if strip:
+            out = torch.empty_like(lay["H"])
+            _lib.check(_lib.lib.slk_hessian_strip_mean(dev.ptr(lay["H"]), dev.ptr(lay["mean"]), n, dev.ptr(out), dev.stream_handle()))
+            lay["H"] = out
+        layers.append({k: lay[k] for k in ("W", "H", "scale")})
+    weights = float(sum(R * n for R, n in shapes))
     for N in Ns:
         nl = int(os.environ.get("NL", "0")) or 1  # bench.py's default
         nf = int(os.environ.get("NF", "3"))
-        backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True, overlap=(nf, nl))
-        fstreams, cstream, lstreams = backend.streams()
-        words = backend.payload_words(n)
-        lo, hi = sdist.row_range(R, 0, N)
+        backend = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=(nf, nl))
+        calls = {"round": 0, "layers_in_rounds": 0, "rows": 0}
+        run_round, run_rows = backend.run_round, backend.run_rows
 
-        only = os.environ.get("ONLY", "")
-        cached = {}
+        def counted_round(members, *a):
+            calls["round"] += 1
+            calls["layers_in_rounds"] += len(members)
+            return run_round(members, *a)
+
+        def counted_rows(*a):
+            calls["rows"] += 1
+            return run_rows(*a)
+
+        backend.run_round, backend.run_rows = counted_round, counted_rows
+        sdist.rehearse = (0, N) if N > 1 else None
 
         def step():
-            here = torch.cuda.current_stream()
-            facs, evs = {}, {}
-            mine = list(range(0, L, N))
-            if only == "loops" and cached:
-                mine = []
-                facs.update(cached["facs"])
-                evs.update(cached["evs"])
-            first = getattr(backend, "_rot", 0)
-            backend._rot = (first + len(mine)) % len(fstreams)
-            for k, l in enumerate(mine):
-                fs = fstreams[(first + k) % len(fstreams)]
-                with torch.cuda.stream(fs):
-                    facs[l] = backend.factorize(layers[l])
-                    evs[l] = torch.cuda.Event()
-                    evs[l].record(fs)
-            if only == "loops" and not cached:
-                cached["facs"], cached["evs"] = dict(facs), dict(evs)
-                mine = list(range(0, L, N))
-            if only == "factor":
-                return None
-            mine = list(range(0, L, N))
-            payloads = {}
-            if N > 1:
-                cevs = {}
-                with torch.cuda.stream(cstream):
-                    for l in mine:
-                        cstream.wait_event(evs[l])
-                        payloads[l] = backend.pack(facs[l], words)
-                        for t in facs[l]:
-                            t.record_stream(cstream)
-                        cevs[l] = torch.cuda.Event()  # one hand-over per round, like the all-gather of that round
-                        cevs[l].record(cstream)
-                cev = cevs[mine[-1]]
-            out = []
-            if N > 1 and os.environ.get("BATCH", "1") != "0":
-                # round by round through the batched loop, as sleekit_amd.dist does (own payload stands in for the peers')
-                for g in range(L // N):
-                    rot = getattr(backend, "_lrot", 0)
-                    backend._lrot = (rot + 1) % len(lstreams)
-                    ls = lstreams[rot]
-                    if os.environ.get("SLOT", "1") != "0":  # (dist.py's default) the round runs on the stream that factored this rank's layer of it
-                        ls = fstreams[(first + g) % len(fstreams)]
-                    with torch.cuda.stream(ls):
-                        ls.wait_event(cevs[mine[g]])
-                        members = list(range(g * N, (g + 1) * N))
-                        out.extend(backend.run_round([layers[l] for l in members], lo, hi, [payloads[mine[g]]] * N))
-                        payloads[mine[g]].record_stream(ls)
-                return out
-            for l in range(L):
-                ls = lstreams[l % len(lstreams)]
-                with torch.cuda.stream(ls):
-                    if N > 1:
-                        ls.wait_event(cev)
-                        root = mine[(l // N) % len(mine)] if l not in facs else l
-                        f = facs[l] if l in facs else backend.unpack(payloads[root], n)
-                        payloads[root].record_stream(ls)
-                    else:
-                        ls.wait_event(evs[l])
-                        f = facs[l]
-                    out.append(backend.run_rows(layers[l], lo, hi, f))
-                    for t in f:
-                        t.record_stream(ls)
-            return out
+            sdist.quantize_stream(layers, backend, join=False)
 
         for _ in range(2):
             step()
         torch.cuda.synchronize()
+        calls.update(round=0, layers_in_rounds=0, rows=0)
         steps = int(os.environ.get("STEPS", "5"))
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -123,8 +86,8 @@ def main():
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / steps
         dev.raise_pending()
-        if "--kernels" in sys.argv:
-            from sleekit_amd import _lib
+        routes = f"{calls['round'] // steps} batched rounds ({calls['layers_in_rounds'] // steps} layers), {calls['rows'] // steps} layers one by one"
+        if "--kernels" in argv:
             _lib.lib.slk_profile_reset()
             _lib.lib.slk_profile_enable(1)
             for _ in range(steps):
@@ -137,8 +100,9 @@ def main():
             for k in rep:
                 print(f"    {k['kernel']:24s} {k['launches'] // steps:5d} launches/step {k['total_ms'] / steps:8.3f} ms  chip {k['chip_ms'] / steps:7.3f} ms")
             _lib.lib.slk_profile_reset()
-        print(f"N={N}: {ms:8.3f} ms per step on one rank  ->  {L * R * n / ms / 1e3:8.0f} Mweights/s whole job "
-              f"(x{(L * R * n / ms / 1e3) / 1:.0f}), payload {words * 8 / 1e6:.0f} MB per layer; host enqueue {host_ms:.2f} ms per step", flush=True)
+        print(f"{cfg or 'headline'} N={N}: {ms:9.3f} ms per step on one rank  ->  {weights / ms / 1e3:8.0f} Mweights/s whole job if the exchange hides; "
+              f"{routes}; host enqueue {host_ms:.2f} ms per step", flush=True)
+    sdist.rehearse = None
 
 
 if __name__ == "__main__":

@@ -78,6 +78,8 @@ enum Opt {
     OPT_NO_BF16_ERROR,         // layer error: float32 MFMA kernel
     OPT_NO_BF16_DMA,           // bfloat16 x 3 GEMMs: stage operands through registers
     OPT_NO_BF16_HESSIAN,       // Hessian accumulation: float32 MFMA kernel
+    OPT_ERROR_F32_BELOW,       // layer error of a batch: float32 kernel when a layer has fewer rows than this (0: 1024, < 0: never)
+    OPT_NO_BF16_ASYM,          // layer error: an H that is not symmetric goes to the float32 kernel
     OPT_COUNT
 };
 int opt(Opt o);

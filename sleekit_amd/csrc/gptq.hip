@@ -395,12 +395,6 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
         // never stored -- and any arithmetic on the loaded value here would make the wave wait for
         // the load at once instead of after the MFMAs of the round before.
         const int cc = min(lo + blk * 16 + lr, hi - 1);
-        if (dbg & 64) {  // EXPERIMENT: contiguous 8 KB per round (wrong values)
-            const double *pk = U + (size_t)a * n + (size_t)((lo - b) / 16 + blk) * 1024 + lk * 16 + lr;
-#pragma unroll
-            for (int s4 = 0; s4 < 16; ++s4) bv[s4] = pk[s4 * 64];
-            return;
-        }
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) {
             const int k = a + 64 * kc + 4 * s4 + lk;
@@ -516,7 +510,11 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
     // deferred part of the last update: Q[:, pm:pc] -= E[:, pa:pb] @ U[pa:pb, pm:pc], of which the
     // first pdone 16-column blocks are done and the rest is due within pleaves more leaves
     int pa = 0, pb = 0, pm = 0, pc = 0, pdone = 0, pleaves = 1;
-    const bool no_updates = dbg & 2, no_leaves = dbg & 1;
+#ifdef SLK_WINDOW_EXPERIMENTS  // measurement builds only: these bits switch parts of the work OFF (wrong values)
+    const bool no_updates = dbg & 2, no_leaves = dbg & 1, no_leaf_regs = dbg & 4;
+#else
+    constexpr bool no_updates = false, no_leaves = false, no_leaf_regs = false;
+#endif
     int sbuf = 0;  // LDS buffer holding the tables of the next staged leaf
 
     // One pass per op plus a final pass that folds in whatever is still pending.  Each pass: at most
@@ -587,7 +585,7 @@ __global__ __launch_bounds__(512) void k_gptq_window(float *__restrict__ Qp, flo
         if (ulo < uhi) run_update(ua, ub, ulo, uhi, uwid, unw, uready);
         if (is_leaf) {
             if (use_fast) {
-                if (!helper && !(dbg & 4)) {
+                if (!helper && !no_leaf_regs) {
                     const int w = op.b - op.a;
                     if (w <= 16) leaf_registers<16>(sm, sm.lt[sbuf], wave, lane, op.a - w0, w, g, inv_step);
                     else leaf_registers<32>(sm, sm.lt[sbuf], wave, lane, op.a - w0, w, g, inv_step);
@@ -874,7 +872,11 @@ extern "C" int slk_gptq_quantize_batch(const float *W, const float *scale, const
     memcpy(&step_bits, &g.step, 4);
     const int fast_ok = table == nullptr && (step_bits & 0x7FFFFFu) != 0x7FFFFFu && g.step > 9.0e-13f && g.step < 1.0e12f &&
                         !opt(OPT_NO_FAST_LEAF);
+#ifdef SLK_WINDOW_EXPERIMENTS
     const int dbg = opt(OPT_WIN_DBG);
+#else
+    const int dbg = opt(OPT_WIN_DBG) & (8 | 16 | 32);  // cycle counters, no L2 warm-up, whole tile loaded up front: same results
+#endif
     const bool no_defer = opt(OPT_NO_DEFER) != 0;
     SLK_LDS_OPT_IN(k_gptq_window<true>, sizeof(WindowSmem));
     SLK_LDS_OPT_IN(k_gptq_window2, sizeof(Window2Smem));

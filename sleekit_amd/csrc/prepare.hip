@@ -151,6 +151,27 @@ __global__ __launch_bounds__(256) void k_load_reversed(const double *__restrict_
 // half of what the square matrix would cost.
 __device__ __forceinline__ size_t tri_offset(size_t i, size_t n) { return i * n - i * (i - 1) / 2; }
 
+// Rows are taken in pairs (i, n - 1 - i): n + 1 elements per pair whatever i, so every workgroup moves the same amount
+// (row by row, the short rows near the bottom left most of a workgroup idle: 65 us for n = 4096 against 38 paired).
+template <class F>
+__device__ __forceinline__ void for_each_upper_pair(int n, F f) {  // f(row, column) for every column >= row of the pairs
+    const int half = (n + 1) / 2;
+    for (int p = blockIdx.x; p < half; p += gridDim.x) {
+        const int i0 = p, i1 = n - 1 - p;
+        const int len0 = n - i0, total = len0 + (i1 != i0 ? n - i1 : 0);
+        for (int e = threadIdx.x; e < total; e += 4 * blockDim.x) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int x = e + h * blockDim.x;
+                if (x < total) {
+                    const bool first = x < len0;
+                    f(first ? i0 : i1, first ? i0 + x : i1 + (x - len0));
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pack_factor(const double *__restrict__ U, const long long *__restrict__ order,
                                                      const int *__restrict__ info, int n, long long *__restrict__ payload) {
     if (blockIdx.x == 0) {
@@ -158,11 +179,7 @@ __global__ __launch_bounds__(256) void k_pack_factor(const double *__restrict__ 
         for (int j = threadIdx.x; j < n; j += blockDim.x) payload[1 + j] = order[j];
     }
     double *tri = reinterpret_cast<double *>(payload + 1 + n);
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const double *src = U + (size_t)i * n;
-        double *dst = tri + tri_offset(i, n) - i;  // dst[j] for j >= i
-        for (int j = i + threadIdx.x; j < n; j += blockDim.x) dst[j] = src[j];
-    }
+    for_each_upper_pair(n, [&](int i, int j) { tri[tri_offset(i, n) - i + j] = U[(size_t)i * n + j]; });
 }
 
 template <bool UPPER_ONLY>
@@ -173,13 +190,11 @@ __global__ __launch_bounds__(256) void k_unpack_factor(const long long *__restri
         for (int j = threadIdx.x; j < n; j += blockDim.x) order[j] = payload[1 + j];
     }
     const double *tri = reinterpret_cast<const double *>(payload + 1 + n);
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        double *dst = U + (size_t)i * n;
-        const double *src = tri + tri_offset(i, n) - i;
-        if (UPPER_ONLY) {  // the part below the diagonal is known to be zero already (a buffer zeroed once and reused)
-            for (int j = i + threadIdx.x; j < n; j += blockDim.x) dst[j] = src[j];
-        } else {
-            for (int j = threadIdx.x; j < n; j += blockDim.x) dst[j] = (j >= i) ? src[j] : 0.0;
+    for_each_upper_pair(n, [&](int i, int j) { U[(size_t)i * n + j] = tri[tri_offset(i, n) - i + j]; });
+    if (!UPPER_ONLY) {  // (UPPER_ONLY: the part below the diagonal is known to be zero already -- a buffer zeroed once and reused)
+        for (int i = blockIdx.x; i < n; i += gridDim.x) {
+            double *dst = U + (size_t)i * n;
+            for (int j = threadIdx.x; j < i; j += blockDim.x) dst[j] = 0.0;
         }
     }
 }

@@ -14,11 +14,15 @@ namespace slk {
 // multiplies by D again and reduces each row over the tile's 128 columns in a fixed
 // order (lane tree, then the two column waves); partial[r][tile] goes to scratch and a
 // second kernel adds the tiles left to right, so results are run-to-run identical.
+struct HPtrs {
+    const float *p[64];  // the Hessians of a batch of layers stacked by rows
+};
+
 __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W, const float *__restrict__ Q,
-                                                     const float *__restrict__ H, int R, int n,
+                                                     const HPtrs hs, int R, int n,
                                                      float *__restrict__ G, float *__restrict__ partial,
                                                      int n_tiles, int vec_ok, const int *__restrict__ sym_flag,
-                                                     int bf16_takes_sym, int p_stride) {
+                                                     int bf16_takes_sym, int p_stride, int rpl) {
     __shared__ Tile128Smem sm;
     __shared__ float rowpart[2][T32];
     // Column tiles are rotated by the row-tile index: with the symmetric shortcut below a tile's
@@ -38,6 +42,9 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
     const int rot = (in_row + tile_y * max(1, n_tiles / 4)) % n_tiles;
     const int tile_x = (tile_y & 1) ? n_tiles - 1 - rot : rot;
     const int r0 = tile_y * T32, j0 = tile_x * T32;
+    const int layer = r0 / rpl;  // rows [b rpl, (b + 1) rpl) belong to layer b (rpl a multiple of the tile when there are several)
+    const float *__restrict__ H = hs.p[layer];
+    if (sym_flag) sym_flag += layer;
     const int t = threadIdx.x;
     Acc128 acc;
     acc.zero();
@@ -46,7 +53,7 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
     //   sum_k D_k H_kj over all k  ==  2 * sum_{k < j0} + the 128-wide diagonal band, after the
     //   final multiplication by D_j and the sum over j.  Halves the flops of the layer error.
     const bool sym = sym_flag != nullptr && sym_flag[0] > 0;  // (a negative verdict = unknown: the general route)
-    if (sym && bf16_takes_sym) return;
+    if (sym && bf16_takes_sym) return;  // (that layer's rows are the bfloat16 kernel's)
     const int kend = sym ? min(j0 + T32, kfull) : kfull;
     const int ksplit = sym ? j0 : 0;  // [0, ksplit) counted twice
     const int a_row = r0 + (t >> 1), a_k = (t & 1) * 8;  // A: D = W - Q, K contiguous
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
                                                           const unsigned short *__restrict__ Hp, int R, int n,
                                                           float *__restrict__ partial, int n_tiles,
                                                           const int *__restrict__ sym_flag, int p_stride, int cb, int rpl,
-                                                          float *__restrict__ G) {
+                                                          float *__restrict__ G, int asym_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TileBf16Smem &sm = *reinterpret_cast<TileBf16Smem *>(smem_raw);
     TileBf16DmaSmem &smd = *reinterpret_cast<TileBf16DmaSmem *>(smem_raw);  // DMA: operands copied to LDS by the loads themselves
@@ -243,7 +250,10 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
     const int r0 = tile_y * T32, j0 = tile_x * T32;
     // a batch of layers stacked by rows (rpl rows each, a multiple of the tile): layer b has its own flag and planes of H
     const int layer = r0 / rpl;
-    if (sym_flag[layer] <= 0) return;
+    // H not symmetric (or not known to be): its planes then hold H^T (k_split3_transposed), every k is multiplied and
+    // nothing counted twice -- when the caller asked for that (asym_mode); otherwise those rows are the float32 kernel's
+    const bool full_k = G != nullptr || sym_flag[layer] <= 0;
+    if (sym_flag[layer] <= 0 && !asym_mode) return;
     Hp += (size_t)layer * 3 * n * n;
     const int t = threadIdx.x;
     Acc128 acc;
@@ -270,8 +280,9 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
     // sum_k D_k H_kj over all k == 2 * sum_{k < j0} + the 128-wide diagonal band (see k_error_tiles)
     const int k_lo = blk_lo * T32, k_below = min(blk_hi * T32, j0);  // [k_lo, k_below) lies under the band: twice
     const unsigned short *a_slabs = Dp + (size_t)tile_y * ksteps * 4096, *b_slabs = Hp + (size_t)tile_x * ksteps * 4096;
-    if (G) {
-        // the product itself is wanted (local search: G = (W - Q) H, obq.py:231): every k, nothing counted twice
+    if (full_k) {
+        // the product itself is wanted (local search: G = (W - Q) H, obq.py:231), or H is not symmetric: every k, nothing
+        // counted twice
         if (DMA)
             tile128_mac_dma(acc, smd, 0, n, a_slabs, d_plane, b_slabs, h_plane);
         else
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
                 for (int r = 0; r < 16; ++r) acc.c[i][j][r] = acc.c[i][j][r] * 2.0f;
         __syncthreads();
     }
-    if (!G && blk_hi == tile_x + 1) {
+    if (!full_k && blk_hi == tile_x + 1) {
         if (DMA)
             tile128_mac_dma(acc, smd, j0, j0 + T32, a_slabs, d_plane, b_slabs, h_plane);
         else
@@ -432,8 +443,10 @@ __global__ __launch_bounds__(256) void k_hessian_tiles(float *__restrict__ H, co
 // (128-feature block ib, 32-token step ks) is [feature in block][32 tokens], contiguous; tokens beyond T are
 // zero.  One workgroup per slab: 32 coalesced rows of 128 floats in, through LDS, 8 KB per plane out.
 __global__ __launch_bounds__(256) void k_split3_transposed(const float *__restrict__ X, int n, int T, int t_first, int t_count,
-                                                           unsigned short *__restrict__ out, size_t plane, int swz) {
+                                                           unsigned short *__restrict__ out, size_t plane, int swz,
+                                                           const int *__restrict__ skip_if_symmetric) {
     __shared__ float tile[32][T32 + 1];
+    if (skip_if_symmetric && skip_if_symmetric[0] > 0) return;  // (the layer error: a symmetric H is split as it stands)
     const int ib = blockIdx.x, ks = blockIdx.y;
     const int t = threadIdx.x;
     for (int e = t; e < 32 * T32; e += 256) {
@@ -570,9 +583,10 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     }
     hipStream_t s = as_stream(stream);
     if (cb > 0) zero_async(partial, (size_t)R * n_slots * sizeof(float), s);  // the float32 kernel fills n_tiles slots only
-    const int rt_layer = (rpl + T32 - 1) / T32;  // row tiles of one layer
-    dim3 grid(8 * ((n_tiles * rt_layer + 7) / 8));  // a multiple of the 8 XCDs: see the tile order in the kernel
+    dim3 grid(8 * ((n_tiles * n_rt + 7) / 8));  // a multiple of the 8 XCDs: see the tile order in the kernel
     bool aligned = ((uintptr_t)W | (uintptr_t)Q) % 16 == 0;
+    HPtrs hp;
+    for (int b = 0; b < 64; ++b) hp.p[b] = b < batch ? Hs[b] : nullptr;
     for (int b = 0; b < batch; ++b) aligned = aligned && (uintptr_t)Hs[b] % 16 == 0;
     const int vec_ok = n % 4 == 0 && aligned;
     const bool try_sym = !opt(OPT_NO_SYM_ERROR);  // (with G too: the bfloat16 kernel needs H symmetric)
@@ -584,19 +598,25 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
         for (int b = 0; b < batch; ++b)
             SLK_RUN("symmetry_check", 0, 4.0 * n * n, s, k_symmetry_flag<<<t64 * (t64 + 1) / 2, 256, 0, s>>>(Hs[b], n, sym + b));
     }
-    // the symmetric case goes to the bfloat16 x 3 kernel when the shape allows (16-byte loads, whole tiles of columns)
+    // the bfloat16 x 3 kernel when the shape allows (16-byte loads, whole tiles of columns).  Its operands are split into
+    // planes first, 10 bytes of traffic per element of H and layer: with few rows per layer (the row shards of a round on
+    // 8 ranks: 512 rows each) that costs more than it saves, and the float32 kernel -- H as it stands, half the products
+    // when H is symmetric -- takes the batch.
+    const int f32_below = opt(OPT_ERROR_F32_BELOW) == 0 ? 1024 : opt(OPT_ERROR_F32_BELOW);
+    const bool few_rows = G == nullptr && batch > 1 && rpl < f32_below;
     const size_t d_plane = (size_t)n_rt * T32 * n;  // rows padded to whole tiles
     unsigned short *Dp = ws.take<unsigned short>(3 * d_plane), *Hp = ws.take<unsigned short>(3 * (size_t)n * n * batch);
-    const int bf16_ok = try_sym && vec_ok && n % T32 == 0 && Dp && Hp && !opt(OPT_NO_BF16_ERROR);
-    if (batch > 1 && !(Dp && Hp)) {
+    const int bf16_ok = try_sym && vec_ok && n % T32 == 0 && Dp && Hp && !opt(OPT_NO_BF16_ERROR) && !few_rows;
+    // a Hessian that is NOT symmetric stays on the bfloat16 kernel too (planes of H^T, every k) unless K is cut into chunks
+    const int asym_mode = bf16_ok && cb == 0 && !opt(OPT_NO_BF16_ASYM);
+    if (batch > 1 && !few_rows && !(Dp && Hp)) {
         set_error("workspace too small for the operand planes of %d layers (slk_workspace_bytes_batch)", batch);
         return SLK_E_WS;
     }
-    // one layer's rows through the float32 kernel (every k when its H is not symmetric)
-    auto f32_layer = [&](int b, const int *flag, int bf16_takes_sym) {
-        const size_t o = (size_t)b * rpl;
-        k_error_tiles<<<grid, 256, 0, s>>>(W + o * n, Q + o * n, Hs[b], rpl, n, G, partial + o * n_slots, n_tiles, vec_ok, flag,
-                                           bf16_takes_sym, n_slots);
+    // every layer's rows through the float32 kernel in one launch (those whose flag says "symmetric" are skipped when
+    // the bfloat16 kernel has taken them)
+    auto f32_all = [&](const int *flags, int bf16_takes_sym) {
+        k_error_tiles<<<grid, 256, 0, s>>>(W, Q, hp, R, n, G, partial, n_tiles, vec_ok, flags, bf16_takes_sym, n_slots, rpl);
     };
     // algorithmic flops: the definition (2 R n^2) whichever way they are obtained
     if (bf16_ok) {
@@ -604,26 +624,30 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
         SLK_LDS_OPT_IN(k_error_tiles_bf16<true>, sizeof(TileBf16DmaSmem));
         const int dma = !opt(OPT_NO_BF16_DMA);  // operands to LDS by global_load_lds (swizzled planes)
         SLK_RUN("error_split", 0, 14.0 * R * n, s,
-                k_split3<<<2048, 256, 0, s>>>(W, Q, R, n, Dp, d_plane, batch == 1 ? sym : nullptr, dma));
-        for (int b = 0; b < batch; ++b)
+                k_split3<<<2048, 256, 0, s>>>(W, Q, R, n, Dp, d_plane, batch == 1 && !asym_mode ? sym : nullptr, dma));
+        for (int b = 0; b < batch; ++b) {
             SLK_RUN("error_split", 0, 10.0 * n * n, s,
                     k_split3<<<2048, 256, 0, s>>>(Hs[b], nullptr, n, n, Hp + (size_t)b * 3 * n * n, (size_t)n * n, sym + b, dma));
+            if (asym_mode)  // (returns at once when the flag says symmetric)
+                SLK_RUN("error_split_t", 0, 0, s,
+                        k_split3_transposed<<<dim3(n / T32, n / 32), 256, 0, s>>>(Hs[b], n, n, 0, n, Hp + (size_t)b * 3 * n * n,
+                                                                                 (size_t)n * n, dma, sym + b));
+        }
         // flops as executed: six bfloat16 products per float32 product, over k <= j only (the definition of the
         // layer error, SURVEY.md 8d, counts 2 R n^2 float32 flops: a third of this, twice over)
         const int wgs = cb > 0 ? n_rt * n_slots : 8 * ((n_rt + 7) / 8) * ((n_tiles + 7) / 8 * 8);  // see the tile order in the kernel
         if (dma)
             SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, cb > 0 ? wgs : n_rt * n_tiles, s,
                       k_error_tiles_bf16<true><<<wgs, 256, sizeof(TileBf16DmaSmem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym, n_slots,
-                                                                                         cb, rpl, G));
+                                                                                         cb, rpl, G, asym_mode));
         else
             SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, cb > 0 ? wgs : n_rt * n_tiles, s,
                       k_error_tiles_bf16<false><<<wgs, 256, sizeof(TileBf16Smem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym, n_slots,
-                                                                                        cb, rpl, G));
-        for (int b = 0; b < batch; ++b) SLK_RUN("error_gemm_f32", 0, 0, s, f32_layer(b, sym + b, 1));
+                                                                                        cb, rpl, G, asym_mode));
+        if (!asym_mode) SLK_RUN("error_gemm_f32", 0, 0, s, f32_all(sym, 1));
     } else {
-        for (int b = 0; b < batch; ++b)
-            SLK_RUN("error_gemm", 2.0 * rpl * n * n, 8.0 * rpl * n + 4.0 * n * n + (G ? 4.0 * rpl * n : 0.0), s,
-                    f32_layer(b, try_sym && G == nullptr ? sym + b : nullptr, 0));  // (its symmetric shortcut does not produce G)
+        SLK_RUN("error_gemm", 2.0 * R * n * n, 8.0 * R * n + 4.0 * n * n * batch + (G ? 4.0 * R * n : 0.0), s,
+                f32_all(try_sym && G == nullptr ? sym : nullptr, 0));  // (its symmetric shortcut does not produce G)
     }
     SLK_RUN("error_reduce", 0, 4.0 * R * n_slots, s, k_error_reduce<<<(R + 255) / 256, 256, 0, s>>>(partial, R, n_slots, row_err));
     return SLK_OK;
@@ -676,7 +700,7 @@ int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, 
             const int cnt = T - t0 < chunk ? T - t0 : chunk, ksteps = (cnt + 31) / 32;
             const size_t plane = (size_t)n * ksteps * 32;
             SLK_RUN("hessian_split", 0, 10.0 * cnt * n, s,
-                    k_split3_transposed<<<dim3(m, ksteps), 256, 0, s>>>(X, n, T, t0, cnt, Xp, plane, dma));
+                    k_split3_transposed<<<dim3(m, ksteps), 256, 0, s>>>(X, n, T, t0, cnt, Xp, plane, dma, nullptr));
             // the running-mean factor applies once per batch: later chunks add to what the first one scaled
             if (dma)
                 SLK_RUN("hessian_syrk_bf16", 6.0 * cnt * n * (n + (double)T32), 6.0 * cnt * n + 8.0 * n * n, s,

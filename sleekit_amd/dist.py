@@ -33,7 +33,14 @@ _rehearsal_payloads = {}
 
 
 class _Done:
+    """Stands in for the work handle of a collective: wait() orders the current stream behind `event`."""
+
+    def __init__(self, event=None):
+        self.event = event
+
     def wait(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
         return True
 
 
@@ -254,7 +261,11 @@ class _NullCtx:
 def _all_gather_words(payload, size):
     """All-gather equal-sized int64 buffers; returns (list of per-rank views, async work)."""
     if rehearse is not None:
-        return [payload] * size, _Done()
+        ev = None
+        if payload.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        return [payload] * size, _Done(ev)
     if dist.get_backend() == "nccl":
         out = torch.empty(size * payload.numel(), dtype=payload.dtype, device=payload.device)
         work = dist.all_gather_into_tensor(out, payload, async_op=True)

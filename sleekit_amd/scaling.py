@@ -1,8 +1,11 @@
 """Drop-in for `sleekit.scaling`: per-row scaling around the quantization loop, on the GPU.
 
-Same names, arguments and defaults as the reference module (sleekit/scaling.py).  The device
-path scales axis 0 of a 2-D weight matrix -- the only layout the callers use (`Sleekit.quantize`
-flattens conv weights first, statistics.py:166).
+Same names, arguments and defaults as the reference module (sleekit/scaling.py).  The kernels
+scale the rows of a 2-D matrix (axis 0: the layout every caller uses -- `Sleekit.quantize` flattens conv
+weights first, statistics.py:166); any other axis or rank is brought to that form by a device-side
+transpose and back (a cold path).  Row sums follow NumPy's pairwise order for axis 0 of a 2-D array; for
+other axes NumPy reduces in another order, so `compute_norm_scaling` then agrees to float32 rounding, not
+bit for bit (minima and maxima are exact either way).
 
 Known deviations, all confined to the scale SEARCH helpers (the quantization path itself is
 bit-exact): Hessians are taken in float32 (the reference's `hessianN` / float64-diagonal variants
@@ -19,29 +22,47 @@ from . import engine
 from .obq import _quantize_opt_block, compute_hessian_chol, compute_hessian_order, quantize_opt  # noqa: F401
 
 
-def _check_axis0(data, scale, axis):
-    assert scale.ndim == 1
-    if axis != 0 or data.ndim != 2:
-        raise NotImplementedError("the device path scales axis 0 of a 2-D weight matrix (what the hot path uses)")
-    assert data.shape[0] == scale.shape[0]
+def _as_rows(data, axis):
+    """`data` on the device as a contiguous 2-D matrix whose rows are the slices along `axis` (scaling.py:11-18:
+    a scale has one entry per index of that axis)."""
+    x = dev.to_device(data)
+    assert -x.ndim <= axis < x.ndim
+    axis %= x.ndim
+    if x.ndim == 2 and axis == 0:
+        return x
+    return x.movedim(axis, 0).reshape(x.shape[axis], -1).contiguous()
 
 
-def _rows_only(data, axis):
-    if axis != 0 or data.ndim != 2:
-        raise NotImplementedError("the device path scales axis 0 of a 2-D weight matrix (what the hot path uses)")
+def _from_rows(rows, shape, axis):
+    """Inverse of _as_rows: back to an array of `shape` with the rows along `axis`."""
+    axis %= len(shape)
+    if len(shape) == 2 and axis == 0:
+        return rows
+    moved = (shape[axis],) + tuple(d for i, d in enumerate(shape) if i != axis)
+    return rows.view(moved).movedim(0, axis).contiguous()
+
+
+def _need_matrix(data, axis):
+    """The GPTQ-style functions take a 2-D weight matrix (rows = output channels along `axis`)."""
+    assert data.ndim == 2
+    return _as_rows(data, axis)
 
 
 def apply_scaling(data, scale, axis=0):
     """data / scale broadcast along `axis` (sleekit/scaling.py:21-25)."""
-    _check_axis0(data, scale, axis)
-    out = engine.rows_divide(dev.to_device(data), dev.to_device(scale))
-    return dev.like_input(out, data)
+    assert scale.ndim == 1
+    rows = _as_rows(data, axis)
+    assert rows.shape[0] == scale.shape[0]
+    out = engine.rows_divide(rows, dev.to_device(scale))
+    return dev.like_input(_from_rows(out, tuple(data.shape), axis), data)
 
 
 def apply_scaling_in_place(data, scale, axis=0):
     """In-place variant (sleekit/scaling.py:28-32)."""
-    _check_axis0(data, scale, axis)
-    out = engine.rows_divide(dev.to_device(data), dev.to_device(scale))
+    assert scale.ndim == 1
+    rows = _as_rows(data, axis)
+    assert rows.shape[0] == scale.shape[0]
+    out = _from_rows(engine.rows_divide(rows, dev.to_device(scale)), tuple(data.shape), axis)
     if dev.is_device_tensor(data):
         data.copy_(out)
     else:
@@ -49,9 +70,8 @@ def apply_scaling_in_place(data, scale, axis=0):
 
 
 def compute_norm_scaling(data, axis=0):
-    """Scale that brings the mean square of every row to 1 (sleekit/scaling.py:35-41)."""
-    _rows_only(data, axis)
-    W = dev.to_device(data)
+    """Scale that brings the mean square of every slice along `axis` to 1 (sleekit/scaling.py:35-41)."""
+    W = _as_rows(data, axis)
     out = torch.empty(W.shape[0], dtype=torch.float32, device=W.device)
     _lib.check(_lib.lib.slk_scale_norm(dev.ptr(W), W.shape[0], W.shape[1], dev.ptr(out), dev.stream_handle()))
     return dev.like_input(out, data)
@@ -71,8 +91,7 @@ def _no_clip_scale(W, codebook):
 
 def compute_non_saturating_scaling(data, codebook, axis=0):
     """Largest-magnitude scale with no saturation (sleekit/scaling.py:44-55)."""
-    _rows_only(data, axis)
-    return dev.like_input(_no_clip_scale(dev.to_device(data), codebook), data)
+    return dev.like_input(_no_clip_scale(_as_rows(data, axis), codebook), data)
 
 
 def quantize_with_scaling(data, scale, quantizer, H=None, act_order="diag", damp=0.01, nb_ls_moves=0):
@@ -113,9 +132,8 @@ def _search_over(W, base, factors, error_of_scale):
 
 def compute_min_mse_scaling(data, codebook, axis=0, H=None, min_factor=0.05, max_factor=1.0, grid_size=100):
     """Scale minimising the (Hessian-weighted) squared error of round-to-nearest (sleekit/scaling.py:98-134)."""
-    _rows_only(data, axis)
     cb_abi = engine.require_uniform(codebook)
-    W = dev.to_device(data)
+    W = _as_rows(data, axis) if H is None else _need_matrix(data, axis)
     R, n = W.shape
     base = _no_clip_scale(W, codebook)
     factors = np.linspace(min_factor, max_factor, grid_size, dtype=np.float32)
@@ -145,9 +163,8 @@ def compute_min_mse_scaling(data, codebook, axis=0, H=None, min_factor=0.05, max
 
 def compute_obq_scaling(data, codebook, axis, H, damp=0.01, act_order="diag", min_factor=0.05, max_factor=1.0, grid_size=100):
     """Scale minimising the error AFTER the GPTQ loop (sleekit/scaling.py:137-190): one factor, 100 loops."""
-    _rows_only(data, axis)
     cb_abi = engine.require_uniform(codebook)
-    W, Hd = dev.to_device(data), dev.to_device(H)
+    W, Hd = _need_matrix(data, axis), dev.to_device(H)
     R, n = W.shape
     base = _no_clip_scale(W, codebook)
     mode = engine.order_mode_code(act_order)

@@ -88,6 +88,44 @@ def test_scale_helpers_and_rtn(amd, pieces):
     assert np.array_equal(W2, pieces["scale/apply"])
 
 
+def test_scaling_along_any_axis(amd):
+    """The reference's own known-answer tests for the axis argument (tests/test_scaling.py:16-72), plus an
+    apply / in-place round trip on a 4-D array against NumPy's broadcasting."""
+    sc_mod = amd.scaling
+    data = np.array([[0.0, 10.0], [5.0, 5.0]], dtype=np.float32)
+    sc = sc_mod.compute_norm_scaling(data, 0)
+    assert np.allclose(sc, [10.0 / np.sqrt(2), 5.0])
+    scaled = sc_mod.apply_scaling(data, sc, 0)
+    assert np.allclose(scaled, [[0.0, np.sqrt(2)], [1.0, 1.0]]) and np.allclose(sc_mod.apply_scaling(scaled, 1 / sc, 0), data)
+    sc = sc_mod.compute_norm_scaling(data, 1)
+    assert np.allclose(sc, [5.0 / np.sqrt(2), np.sqrt(125 / 2)])
+    scaled = sc_mod.apply_scaling(data, sc, 1)
+    assert np.allclose(scaled, [[0.0, 10.0 / np.sqrt(125 / 2)], [np.sqrt(2), 5.0 / np.sqrt(125 / 2)]])
+    assert np.allclose(sc_mod.apply_scaling(scaled, 1 / sc, 1), data)
+    rng = np.random.default_rng(8)
+    big = rng.standard_normal((10, 20, 30, 40)).astype(np.float32)
+    for axis in range(4):
+        sc = sc_mod.compute_norm_scaling(big, axis)
+        rest = tuple(i for i in range(4) if i != axis)
+        assert len(sc) == big.shape[axis] and np.allclose(sc, np.sqrt(np.square(big).mean(axis=rest)), rtol=1e-6)
+        shape = [1, 1, 1, 1]
+        shape[axis] = -1
+        assert np.array_equal(sc_mod.apply_scaling(big, sc, axis), big / sc.reshape(shape))
+        copy = big.copy()
+        sc_mod.apply_scaling_in_place(copy, sc, axis)
+        assert np.array_equal(copy, big / sc.reshape(shape))
+    table = np.array([[0.0, 10.0, -20.0, 15.0], [5.0, 5.0, 10.0, -10.0], [1.0, 2.0, -4.0, 3.0], [0.0, 0.0, 0.0, 0.0],
+                      [1.0, 10.0, 100.0, 1000.0], [-1.0, 10.0, 100.0, 1000.0]], dtype=np.float32)
+    cb = amd.codebook.Codebook([-1.0, 0.0, 10.0, 20.0])
+    assert np.allclose(sc_mod.compute_non_saturating_scaling(table, cb, 0), [20, 10, 4, 1e-16, 50, 50])
+    assert np.allclose(sc_mod.compute_non_saturating_scaling(table, cb, 1), [1, 0.5, 20, 50])
+    # quantization along axis 1 == along axis 0 of the transpose
+    ucb = amd.codebook.UniformCodebook(8, -1, 1)
+    W = (rng.standard_normal((24, 40)) * 0.1).astype(np.float32)
+    assert np.array_equal(sc_mod.compute_min_mse_scaling(W, ucb, axis=1, grid_size=20),
+                          sc_mod.compute_min_mse_scaling(np.ascontiguousarray(W.T), ucb, axis=0, grid_size=20))
+
+
 def test_scale_selection(amd, pieces):
     """closed-form scales and the grid searches, against the reference's outputs."""
     L = layer(64, 96, 2001)
@@ -430,10 +468,25 @@ def test_layer_error_bf16_path(amd, slkopt):
     slkopt.delenv("SLK_NO_ERROR_SPLITK")
     np.testing.assert_allclose(whole, want, rtol=1e-5)
     np.testing.assert_allclose(got, whole, rtol=2e-6)
-    Ha = H.copy()
-    Ha[3, 7] += np.float32(0.25)  # not symmetric: every k is multiplied
+    # not symmetric: every k is multiplied -- on the bfloat16 MFMA from planes of H^T (default), on the float32 MFMA
+    # (switch), and with the K-chunked few-row layout (which sends such a layer to the float32 kernel)
+    Ha = (H + np.float32(0.05) * np.triu(rng.standard_normal((n, n)).astype(np.float32), 1)).astype(np.float32)
+    Ha[3, 7] += np.float32(0.25)
     want_a = ((D @ Ha.astype(np.float64)) * D).sum(axis=1)
-    np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, Ha), want_a, rtol=1e-5)
+    got_a = amd.obq.channelwise_error(W, Q, Ha)
+    np.testing.assert_allclose(got_a, want_a, rtol=1e-5)
+    slkopt.setenv("SLK_NO_BF16_ASYM", "1")
+    np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, Ha), got_a, rtol=4e-6)
+    slkopt.delenv("SLK_NO_BF16_ASYM")
+    # the product itself (what the local search starts from): G = (W - Q) @ Ha, both routes
+    Wd, Qd, Hd = (torch.from_numpy(x).cuda() for x in (W, Q, Ha))
+    _, G1 = amd.engine.row_errors(Wd, Qd, Hd, want_G=True)
+    slkopt.setenv("SLK_NO_BF16_ASYM", "1")
+    _, G2 = amd.engine.row_errors(Wd, Qd, Hd, want_G=True)
+    slkopt.delenv("SLK_NO_BF16_ASYM")
+    Gw = D @ Ha.astype(np.float64)
+    bound = 4.0 * 2.0 ** -24 * (np.abs(D) @ np.abs(Ha.astype(np.float64)))
+    assert (np.abs(G1.cpu().numpy() - Gw) <= bound).all() and (np.abs(G2.cpu().numpy() - Gw) <= bound).all()
 
 
 def test_table_codebook(amd, pieces):
@@ -802,6 +855,10 @@ def test_batch_entry_points(amd, B, R, n, levels):
     flags = torch.cat([eng.symmetry_flag(H) for H in Hs])
     assert flags.tolist() == [1] * (B - 1) + [0]
     assert torch.equal(eng.row_errors_batch(W, Q, Hs, flags), err)  # verdicts handed in: same route, same sums
+    # few rows per layer take the float32 kernel (H as it stands, one launch for the batch); the bfloat16 x 3 route forced
+    # instead must agree
+    with amd.lib.option("error_f32_below", -1):
+        np.testing.assert_allclose(eng.row_errors_batch(W, Q, Hs, flags).cpu().numpy(), err.cpu().numpy(), rtol=4e-6)
     for b in range(B):
         want = ((W[b] - Q[b]).double() @ Hs[b].double() * (W[b] - Q[b]).double()).sum(dim=1)
         np.testing.assert_allclose(err[b].cpu().numpy(), want.cpu().numpy(), rtol=1e-5)

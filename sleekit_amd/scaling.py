@@ -9,8 +9,10 @@ bit for bit (minima and maxima are exact either way).
 
 Known deviations, all confined to the scale SEARCH helpers (the quantization path itself is
 bit-exact): Hessians are taken in float32 (the reference's `hessianN` / float64-diagonal variants
-promote to float64), and `compute_obq_scaling` evaluates errors in the original column order
-instead of the permuted one (same sums, different float32 summation order).
+promote to float64), and the searches whose errors come out of a Hessian product (`hessian*`, `obq`)
+pick among grid points whose errors are GEMM results -- summed in this library's order, not the BLAS's --
+so a row whose two best grid points tie to within that rounding may take the other one
+(tests/test_gpu_parity.py::test_scale_selection proves each such row against the reference's own errors).
 """
 
 import numpy as np  # noqa: F401  (star-importers of the reference rely on `np` leaking from here)
@@ -117,16 +119,31 @@ def _times(a, b=None, c=0.0):
     return out
 
 
-def _search_over(W, base, factors, error_of_scale):
-    """Grid search with row errors produced by `error_of_scale(scale)` (full-Hessian and OBQ variants)."""
-    R = W.shape[0]
+_STACK_BYTES = 1 << 30  # budget for one stacked copy of W in the grid searches below
+
+
+def _search_stacked(W, base, factors, H, quantize_rows):
+    """Grid search whose row errors come out of a Hessian product (full-Hessian and OBQ-aware variants,
+    scaling.py:98-134 and 160-190), with the grid points stacked by ROWS: rows never interact and W, H (and the
+    factor U) are shared, so a chunk of G grid points is ONE matrix of G R rows with scales f_g * base -- one call
+    of `quantize_rows(W_stack, scales)` (-> de-quantized rows) and one layer-error product per chunk instead of one
+    per grid point, nothing but kernel launches from the host.  The first minimum wins, like the reference's `<`."""
+    R, n = W.shape
+    s = dev.stream_handle()
     best_err = torch.empty(R, dtype=torch.float32, device=W.device)
     best_f = torch.empty(R, dtype=torch.float32, device=W.device)
-    s = dev.stream_handle()
     _lib.check(_lib.lib.slk_search_step(None, 0.0, R, dev.ptr(best_err), dev.ptr(best_f), 1, s))
-    for f in factors:
-        err = error_of_scale(_times(base, None, f))
-        _lib.check(_lib.lib.slk_search_step(dev.ptr(err), float(f), R, dev.ptr(best_err), dev.ptr(best_f), 0, s))
+    per = int(max(1, min(len(factors), _STACK_BYTES // (4 * R * n), (1 << 30) // max(R, 1))))
+    fac = torch.from_numpy(np.ascontiguousarray(factors, dtype=np.float32)).to(W.device)
+    for c0 in range(0, len(factors), per):
+        f = fac[c0:c0 + per]
+        G = f.numel()
+        scales = (f[:, None] * base[None, :]).reshape(-1)  # float32 products, like `s * initial_scale`
+        Wst = W.unsqueeze(0).expand(G, R, n).reshape(G * R, n)
+        err = engine.row_errors(quantize_rows(Wst, scales), Wst, H)
+        for g in range(G):
+            _lib.check(_lib.lib.slk_search_step(err[g * R:(g + 1) * R].data_ptr(), float(factors[c0 + g]), R, dev.ptr(best_err),
+                                                dev.ptr(best_f), 0, s))
     return _times(base, best_f)
 
 
@@ -154,11 +171,11 @@ def compute_min_mse_scaling(data, codebook, axis=0, H=None, min_factor=0.05, max
     assert H.ndim == 2 and H.shape[0] == H.shape[1] == n
     Hd = dev.to_device(H)
 
-    def error_of(scale):
-        q = codebook.quantize_value(engine.rows_divide(W, scale))
-        return engine.row_errors(engine.rows_divide(q, scale, invert=True), W, Hd)
+    def rtn_rows(Wst, scales):
+        q = codebook.quantize_value(engine.rows_divide(Wst, scales))
+        return engine.rows_divide(q, scales, invert=True)
 
-    return dev.like_input(_search_over(W, base, factors, error_of), data)
+    return dev.like_input(_search_stacked(W, base, factors, Hd, rtn_rows), data)
 
 
 def compute_obq_scaling(data, codebook, axis, H, damp=0.01, act_order="diag", min_factor=0.05, max_factor=1.0, grid_size=100):
@@ -177,12 +194,15 @@ def compute_obq_scaling(data, codebook, axis, H, damp=0.01, act_order="diag", mi
     order, U, info = engine.factorize(Hd, n, damp, mode, miss)
     dev.note_info(info, "compute_hessian_chol")
     factors = np.linspace(min_factor, max_factor, grid_size, dtype=np.float32)
+    # like the reference (scaling.py:170-172): W and H go into the processing order ONCE, the loop then runs in place
+    # (identity order) and the errors are evaluated on the permuted pair
+    Wp = W.index_select(1, order)
+    Hp = Hd.index_select(0, order).index_select(1, order)
 
-    def error_of(scale):
-        Q, _, _ = engine.run_loop(W, scale, order, U, cb_abi, 32, 8, want_idx=False)
-        return engine.row_errors(engine.rows_divide(Q, scale, invert=True), W, Hd)
+    def loop_rows(Wst, scales):
+        return engine.run_loop(Wst, scales, None, U, cb_abi, 32, 8, want_idx=False, unscale=True)[0]
 
-    return dev.like_input(_search_over(W, base, factors, error_of), data)
+    return dev.like_input(_search_stacked(Wp, base, factors, Hp, loop_rows), data)
 
 
 def compute_scaling(data, codebook, H, mode="mse", axis=0, min_factor=0.05, max_factor=1.0, grid_size=100):

@@ -254,6 +254,30 @@ def pieces():
     for mode in ("mse", "diag", "hessian", "diag3", "hessian1"):
         P[f"scale/search_{mode}"] = ref_scaling.compute_scaling(L["W"], cb, L["H"], mode=mode, grid_size=20)
     P["scale/search_obq"] = ref_scaling.compute_scaling(L["W"], cb, L["H"], mode="obq", grid_size=10)
+    # the same two searches step by step (the reference's own functions in its own order, scaling.py:98-134, 160-190),
+    # keeping every grid point's row errors: what lets a test PROVE that a row whose chosen factor differs sits on a
+    # near-tie of the reference's own errors (they come out of a BLAS product, whose summation order is not ours)
+    for mode, gs in (("hessian", 20), ("obq", 10)):
+        base = ref_scaling.compute_non_saturating_scaling(L["W"], cb, 0)
+        factors = np.linspace(0.05, 1.0, gs, dtype=np.float32)
+        errs = []
+        if mode == "obq":
+            H_opt = L["H"] + 0.01 * L["H"].diagonal().mean() * np.eye(L["H"].shape[0])
+            order = ref_obq.compute_hessian_order(ref_scaling.apply_scaling(L["W"], base, 0), H_opt, cb, "diag")
+            Wp, Hp = L["W"][:, order], L["H"][order][:, order]
+            Hinv = ref_obq.compute_hessian_chol(H_opt[order][:, order])
+        for f in factors:
+            sc = f * base
+            if mode == "obq":
+                Q = ref_scaling.apply_scaling(Wp, sc, 0)
+                ref_obq._quantize_opt_block(Q, np.zeros_like(Wp), Hinv, cb, min_block_size=32, num_blocks=8)
+                errs.append(ref_scaling._compute_mse(Hp, ref_scaling.apply_scaling(Q, 1 / sc, 0) - Wp))
+            else:
+                errs.append(ref_scaling._compute_mse(L["H"], ref_scaling.quantize_with_scaling(L["W"], sc, cb) - L["W"]))
+        errs = np.stack(errs)
+        pick = factors[np.argmin(errs, axis=0)]  # first minimum, like the reference's strict `<`
+        assert np.array_equal(base * pick, P[f"scale/search_{mode}"]), mode
+        P[f"scale/search_{mode}_errors"], P[f"scale/search_{mode}_factors"], P[f"scale/search_{mode}_base"] = errs, factors, base
 
     # --- gains (obq.py:220-231) ---
     Q0 = cb(ref_scaling.apply_scaling(L["W"], L["scale"], 0))

@@ -157,7 +157,9 @@ def main():
     weights_per_step = float(sum(R * n for R, n in shapes))
 
     # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: one loop stream; the batched rounds run on the factor streams)
-    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else ((3, 3) if launch_bound else (3, 1))
+    # (on 8 ranks a rank factors ONE layer per round and runs the round's loop on that factor stream: two such chains in
+    # flight measured best -- 4.9 ms per step against 5.7 ... 6.8 with three, tools/micro_rank_of_n.py, NF = 1 ... 4)
+    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else ((3, 3) if launch_bound else ((2, 1) if world >= 8 else (3, 1)))
     backend = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=streams)
 
     in_flight = []  # per enqueued step: events at the tail of its loop streams

@@ -54,7 +54,7 @@ def main():
     weights = float(sum(R * n for R, n in shapes))
     for N in Ns:
         nl = int(os.environ.get("NL", "0")) or 1  # bench.py's default
-        nf = int(os.environ.get("NF", "3"))
+        nf = int(os.environ.get("NF", "0")) or (2 if N >= 8 else 3)  # bench.py's default
         backend = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=(nf, nl))
         calls = {"round": 0, "layers_in_rounds": 0, "rows": 0}
         run_round, run_rows = backend.run_round, backend.run_rows

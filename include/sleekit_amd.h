@@ -61,7 +61,8 @@ typedef void *slk_stream_t;
 /* Library / device ---------------------------------------------------------
  * slk_abi_version: 4.  History: 2 = every quantizing entry takes (levels, lo, hi, table); 3 adds the batch forms
  * (slk_gptq_quantize_batch, slk_row_errors_batch, slk_workspace_bytes_batch) and slk_symmetry_flag; 4 adds the
- * `trace` argument of slk_local_search and slk_set_option / slk_get_option.                                    */
+ * `trace` argument of slk_local_search, slk_set_option / slk_get_option and the batched factorisation
+ * (slk_hessian_prepare_batch, slk_chol_inverse_upper_batch, slk_factor_workspace_bytes_batch).                 */
 int slk_abi_version(void);
 const char *slk_last_error(void);
 /* Run-time switches between code paths that give the same results (the tests hold them to that) or that shape a
@@ -141,6 +142,18 @@ int slk_factor_load(const double *M, int n, double *A, slk_stream_t stream);
  *     pivot appeared -- the reference raises numpy.linalg.LinAlgError there.    */
 int slk_chol_inverse_upper(double *A, int n, double *U, int *info, void *workspace,
                            size_t ws_bytes, slk_stream_t stream);
+
+/* (a3-a6 for `batch` layers of ONE width n at once: every launch covers all the layers -- blockIdx.z is the layer --
+ * so a round of small layers costs the launches of one.  Small layers are bound by the host's launch rate, not by the
+ * GPU (a 768-column layer is ~50 launches of a few microseconds each): OPT-125M's 72 layers go from 48 ms to the time
+ * of ~10 rounds.  H: HOST array of `batch` device pointers; order_out batch x n; A batch x ld x ld (ld = slk_factor_ld(n));
+ * U batch x n x n; info `batch` ints.  Orders: SLK_ORDER_NONE / SLK_ORDER_DIAG.  Same results as the single-layer calls.
+ * Workspace: slk_factor_workspace_bytes_batch(batch, n).                                                          */
+int slk_hessian_prepare_batch(const float *const *H, int batch, int n, float damp, int order_mode,
+                              long long *order_out, double *A, void *workspace, size_t ws_bytes, slk_stream_t stream);
+int slk_chol_inverse_upper_batch(double *A, int batch, int n, double *U, int *info, void *workspace,
+                                 size_t ws_bytes, slk_stream_t stream);
+size_t slk_factor_workspace_bytes_batch(int batch, int n);
 
 /* Multi-GPU payload of one layer's factor: one buffer of 8-byte words,
  *   [0] status word, [1..n] order, then the upper triangle of U row by row,

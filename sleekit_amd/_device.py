@@ -72,6 +72,17 @@ def workspace(R, n, batch=1):
     return ws, ws.numel()
 
 
+def scratch(nbytes, tag="scratch"):
+    """(tensor, bytes): grow-only scratch of at least `nbytes` per (device, stream, tag)."""
+    dev = require_gpu()
+    key = (dev.index, stream_handle(), tag)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws, ws.numel()
+
+
 def release_workspaces():
     _workspaces.clear()
 

@@ -46,6 +46,9 @@ PROTOTYPES = {
     "slk_factor_ld": (c_int, [c_int]),
     "slk_factor_load": (c_int, [P, c_int, P, P]),
     "slk_chol_inverse_upper": (c_int, [P, c_int, P, P, P, c_size_t, P]),
+    "slk_hessian_prepare_batch": (c_int, [P, c_int, c_int, c_float, c_int, P, P, P, c_size_t, P]),
+    "slk_chol_inverse_upper_batch": (c_int, [P, c_int, c_int, P, P, P, c_size_t, P]),
+    "slk_factor_workspace_bytes_batch": (c_size_t, [c_int, c_int]),
     "slk_factor_payload_words": (c_size_t, [c_int]),
     "slk_factor_pack": (c_int, [P, P, P, c_int, P, P]),
     "slk_factor_unpack": (c_int, [P, c_int, P, P, P, P]),

@@ -89,6 +89,12 @@ int opt(Opt o);
 hipError_t lds_opt_in(const void *kernel, size_t bytes);
 #define SLK_LDS_OPT_IN(kernel, bytes) SLK_HIP(slk::lds_opt_in(reinterpret_cast<const void *>(kernel), (bytes)))
 
+// The float32 inputs of a batch of layers (caller-owned tensors: no common base), passed by value to the kernels
+// that read them; blockIdx.z is the layer in every batched launch.
+struct PtrTable {
+    const float *p[64];
+};
+
 static inline hipStream_t as_stream(slk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -97,6 +97,10 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
                                                     double *__restrict__ X, int *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PanelSmem &sm = *reinterpret_cast<PanelSmem *>(smem_raw);
+    // (blockIdx.z: the layer of a batched factorisation -- square matrices of one size, one after the other)
+    A += (size_t)blockIdx.z * ld * ld;
+    X += (size_t)blockIdx.z * ld * ld;
+    info += blockIdx.z;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
 
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
 __global__ __launch_bounds__(256) void k_syrk_tiles(double *__restrict__ A, int ld, int ti0, int tj0, int ka,
                                                     int kb) {
     __shared__ __attribute__((aligned(16))) Tile64Smem sm;
+    A += (size_t)blockIdx.z * ld * ld;
     const int bi = ti0 + blockIdx.y, bj = tj0 + blockIdx.x;
     if (bj > bi) return;
     Acc64 acc;
@@ -234,6 +239,7 @@ __global__ __launch_bounds__(256) void k_syrk_tiles(double *__restrict__ A, int 
 // K = 256 the update moves 6.5 flop per operand byte: it runs at the speed of the L2 misses.
 __global__ __launch_bounds__(256) void k_syrk_triangle(double *__restrict__ A, int ld, int t0, int m, int ka, int kb) {
     __shared__ __attribute__((aligned(16))) Tile64Smem sm;
+    A += (size_t)blockIdx.z * ld * ld;
     const int total = m * (m + 1) / 2, per_xcd = (total + 7) / 8;
     const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (lin >= total) return;
@@ -264,6 +270,9 @@ template <int STAGE>
 __global__ __launch_bounds__(256) void k_trtri_level(const double *__restrict__ L, double *__restrict__ X,
                                                      double *__restrict__ S, int ld, int nt, int s) {
     __shared__ __attribute__((aligned(16))) Tile64Smem sm;
+    L += (size_t)blockIdx.z * ld * ld;
+    X += (size_t)blockIdx.z * ld * ld;
+    S += (size_t)blockIdx.z * ld * ld;
     // block id -> (node, slow, fast): `fast` runs over the s tiles of the balanced direction
     const int id = blockIdx.x;
     const int per_node = s * s, node = id / per_node, in_node = id % per_node;
@@ -297,6 +306,8 @@ __global__ __launch_bounds__(256) void k_trtri_level(const double *__restrict__ 
 // U[i][j] = X[n-1-i][n-1-j] for j >= i, 0 below the diagonal.
 __global__ __launch_bounds__(256) void k_flip_out(const double *__restrict__ X, int ld, int n,
                                                   double *__restrict__ U) {
+    X += (size_t)blockIdx.z * ld * ld;
+    U += (size_t)blockIdx.z * n * n;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const double *src = X + (size_t)(n - 1 - i) * ld;
         double *dst = U + (size_t)i * n;
@@ -304,56 +315,57 @@ __global__ __launch_bounds__(256) void k_flip_out(const double *__restrict__ X, 
     }
 }
 
-__global__ void k_clear_info(int *info) { info[0] = 0; }
+__global__ void k_clear_info(int *info) { info[blockIdx.x] = 0; }
 
 }  // namespace slk
 
 using namespace slk;
 
-extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, void *workspace,
-                                      size_t ws_bytes, slk_stream_t stream) {
-    SLK_REQUIRE(A && U && info && n > 0, "bad arguments");
+static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, void *workspace, size_t ws_bytes,
+                             slk_stream_t stream) {
     const int ld = slk_factor_ld(n);
     const int nt = ld / TILE;
+    const unsigned B = (unsigned)batch;
+    const double Bd = (double)batch;
     Arena ws(workspace, ws_bytes);
-    double *X = ws.take<double>((size_t)ld * ld);
-    double *S = ws.take<double>((size_t)ld * ld);
+    double *X = ws.take<double>((size_t)ld * ld * batch);
+    double *S = ws.take<double>((size_t)ld * ld * batch);
     if (!X || !S) {
-        set_error("workspace too small for the %d x %d factorisation", n, n);
+        set_error("workspace too small for %d factorisation(s) of %d x %d", batch, n, n);
         return SLK_E_WS;
     }
     hipStream_t s = as_stream(stream);
     SLK_LDS_OPT_IN(k_chol_panel, sizeof(PanelSmem));
-    SLK_RUN_W("clear_info", 0, 4, 1, s, k_clear_info<<<1, 1, 0, s>>>(info));
+    SLK_RUN_W("clear_info", 0, 4, 1, s, k_clear_info<<<B, 1, 0, s>>>(info));
 
     for (int K0 = 0; K0 < ld; K0 += OUTER) {
         const int K1 = K0 + OUTER < ld ? K0 + OUTER : ld;
         for (int k0 = K0; k0 < K1; k0 += PANEL) {
             const int below = (ld - k0) / PANEL;  // tiles from the diagonal tile down
             // potf2 + inverse of the 64-tile (2/3 * 64^3) and the triangular product below it
-            SLK_RUN_W("chol_panel", 2.0 / 3.0 * 64 * 64 * 64 + (double)(below - 1) * 64 * 64 * 64, 16.0 * below * 64 * 64, below, s,
-                    k_chol_panel<<<below, 256, sizeof(PanelSmem), s>>>(A, ld, k0, X, info));
+            SLK_RUN_W("chol_panel", Bd * (2.0 / 3.0 * 64 * 64 * 64 + (double)(below - 1) * 64 * 64 * 64), Bd * 16.0 * below * 64 * 64,
+                      below * batch, s, k_chol_panel<<<dim3(below, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, k0, X, info));
             // inner update: columns of this outer block to the right of the panel
             const int tj0 = k0 / TILE + 1, tj1 = K1 / TILE;
             if (tj1 > tj0) {
-                dim3 grid(tj1 - tj0, nt - tj0);
+                dim3 grid(tj1 - tj0, nt - tj0, B);
                 double tiles = 0;
                 for (int bj = tj0; bj < tj1; ++bj) tiles += nt - bj;
-                SLK_RUN_W("chol_syrk_inner", tiles * 2.0 * 64 * 64 * PANEL, 8.0 * (ld - k0) * PANEL + tiles * 16.0 * 64 * 64, tiles, s,
-                        k_syrk_tiles<<<grid, 256, 0, s>>>(A, ld, tj0, tj0, k0, k0 + PANEL));
+                SLK_RUN_W("chol_syrk_inner", Bd * tiles * 2.0 * 64 * 64 * PANEL, Bd * (8.0 * (ld - k0) * PANEL + tiles * 16.0 * 64 * 64),
+                          tiles * batch, s, k_syrk_tiles<<<grid, 256, 0, s>>>(A, ld, tj0, tj0, k0, k0 + PANEL));
             }
         }
         const int t0 = K1 / TILE;
         if (nt > t0) {
             const int m = nt - t0, total = m * (m + 1) / 2;
             const double tiles = total;
-            SLK_RUN_W("chol_syrk_outer", tiles * 2.0 * 64 * 64 * (K1 - K0), 8.0 * (ld - K1) * (K1 - K0) + tiles * 16.0 * 64 * 64, tiles, s,
-                      k_syrk_triangle<<<8 * ((total + 7) / 8), 256, 0, s>>>(A, ld, t0, m, K0, K1));
+            SLK_RUN_W("chol_syrk_outer", Bd * tiles * 2.0 * 64 * 64 * (K1 - K0), Bd * (8.0 * (ld - K1) * (K1 - K0) + tiles * 16.0 * 64 * 64),
+                      tiles * batch, s, k_syrk_triangle<<<dim3(8 * ((total + 7) / 8), 1, B), 256, 0, s>>>(A, ld, t0, m, K0, K1));
         }
     }
     for (int lvl = 1; lvl < nt; lvl *= 2) {
         const int nodes = (nt + 2 * lvl - 1) / (2 * lvl);
-        dim3 grid(nodes * lvl * lvl);
+        dim3 grid(nodes * lvl * lvl, 1, B);
         // work of this level: for every node, tiles (bi in B, bj in A) with their triangular K ranges
         double f0 = 0, f1 = 0, tiles = 0;
         for (int lo = 0; lo + lvl < nt; lo += 2 * lvl) {
@@ -365,9 +377,30 @@ extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, vo
                     tiles += 1;
                 }
         }
-        SLK_RUN_W("trtri_stage0", f0, f0 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64, tiles, s, k_trtri_level<0><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
-        SLK_RUN_W("trtri_stage1", f1, f1 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64, tiles, s, k_trtri_level<1><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
+        SLK_RUN_W("trtri_stage0", Bd * f0, Bd * (f0 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64), tiles * batch, s,
+                  k_trtri_level<0><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
+        SLK_RUN_W("trtri_stage1", Bd * f1, Bd * (f1 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64), tiles * batch, s,
+                  k_trtri_level<1><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
     }
-    SLK_RUN("flip_out", 0, 12.0 * n * n, s, k_flip_out<<<n < 2048 ? n : 2048, 256, 0, s>>>(X, ld, n, U));
+    SLK_RUN("flip_out", 0, Bd * 12.0 * n * n, s, k_flip_out<<<dim3(n < 2048 ? n : 2048, 1, B), 256, 0, s>>>(X, ld, n, U));
     return SLK_OK;
+}
+
+extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, void *workspace,
+                                      size_t ws_bytes, slk_stream_t stream) {
+    SLK_REQUIRE(A && U && info && n > 0, "bad arguments");
+    return chol_inverse_impl(A, 1, n, U, info, workspace, ws_bytes, stream);
+}
+
+extern "C" int slk_chol_inverse_upper_batch(double *A, int batch, int n, double *U, int *info, void *workspace,
+                                            size_t ws_bytes, slk_stream_t stream) {
+    SLK_REQUIRE(A && U && info && n > 0, "bad arguments");
+    SLK_REQUIRE(batch >= 1 && batch <= 64, "batch must be 1..64");
+    return chol_inverse_impl(A, batch, n, U, info, workspace, ws_bytes, stream);
+}
+
+extern "C" size_t slk_factor_workspace_bytes_batch(int batch, int n) {
+    if (batch < 1 || batch > 64 || n <= 0) return 0;
+    const size_t ld = (size_t)slk_factor_ld(n);
+    return 2 * ld * ld * sizeof(double) * batch + (size_t)batch * (64 * sizeof(float) + (size_t)n * (sizeof(double) + sizeof(int))) + (1u << 16);
 }

@@ -9,8 +9,9 @@ typedef float float4v_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ diag mean
 // mean(diag H) in float32 with NumPy's summation order (npsum.h): feeds the damping term.
-__global__ __launch_bounds__(256) void k_diag_mean(const float *__restrict__ H, int n, int ld,
-                                                   float *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_diag_mean(const PtrTable hs, int n, int ld, float *__restrict__ out) {
+    const float *__restrict__ H = hs.p[blockIdx.z];
+    out += 64 * blockIdx.z;
     __shared__ SumTree trees[2];
     __shared__ float terms[NP_CHUNK];
     prepare_trees(trees, n);
@@ -21,9 +22,12 @@ __global__ __launch_bounds__(256) void k_diag_mean(const float *__restrict__ H, 
 // ------------------------------------------------------------------ order keys
 // key[i] = -(double(H_ii) + damp_add) [* double(miss_i)]     (obq.py:64, 69, 81)
 // scal[0] = mean(diag); scal[1] <- damp_add = float32(damp) * mean   (float32 product)
-__global__ __launch_bounds__(256) void k_order_keys(const float *__restrict__ H, int n, float damp,
+__global__ __launch_bounds__(256) void k_order_keys(const PtrTable hs, int n, float damp,
                                                     const float *__restrict__ miss, float *scal,
                                                     double *__restrict__ keys) {
+    const float *__restrict__ H = hs.p[blockIdx.z];
+    scal += 64 * blockIdx.z;
+    keys += (size_t)n * blockIdx.z;
     const float add = damp * scal[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[1] = add;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -47,6 +51,8 @@ __device__ __forceinline__ long long total_order_key(double k) {
 __global__ __launch_bounds__(256) void k_rank_partial(const double *__restrict__ keys, int n, int slice,
                                                       int *__restrict__ rank) {
     __shared__ long long tile[1024];
+    keys += (size_t)n * blockIdx.z;
+    rank += (size_t)n * blockIdx.z;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const long long ki = i < n ? total_order_key(keys[i]) : 0;
     const int j_lo = blockIdx.y * slice, j_hi = min(n, j_lo + slice);
@@ -67,6 +73,8 @@ __global__ __launch_bounds__(256) void k_rank_partial(const double *__restrict__
 
 __global__ __launch_bounds__(256) void k_rank_scatter(const int *__restrict__ rank, int n, int identity,
                                                       long long *__restrict__ order) {
+    rank += (size_t)n * blockIdx.z;
+    order += (size_t)n * blockIdx.z;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) order[identity ? i : rank[i]] = i;
 }
@@ -76,10 +84,14 @@ __global__ __launch_bounds__(256) void k_rank_scatter(const int *__restrict__ ra
 // rows/cols n .. ld-1 are the identity (padding to the factor tile size).
 // The lower triangle of the index-reversed matrix is the triangle LAPACK's
 // potrf('L') reads in the reference (obq.py:47-50), so an asymmetric H gives the same answer.
-__global__ __launch_bounds__(256) void k_gather_reversed(const float *__restrict__ H, int n, int ld,
+__global__ __launch_bounds__(256) void k_gather_reversed(const PtrTable hs, int n, int ld,
                                                          const long long *__restrict__ order,
                                                          const float *__restrict__ scal,
                                                          double *__restrict__ A) {
+    const float *__restrict__ H = hs.p[blockIdx.z];
+    order += (size_t)n * blockIdx.z;
+    scal += 64 * blockIdx.z;
+    A += (size_t)ld * ld * blockIdx.z;
     const double add = (double)scal[1];
     for (int i = blockIdx.x; i < ld; i += gridDim.x) {
         double *row = A + (size_t)i * ld;
@@ -103,10 +115,14 @@ __global__ __launch_bounds__(256) void k_gather_reversed(const float *__restrict
 // 4-byte reads straight from global were one L1/L2 request each), and the tiles strictly above the diagonal,
 // which no kernel of the factorisation reads, are not written at all (the 64 x 64 diagonal tiles are kept whole:
 // the trailing update reads and rewrites them entirely).  n % 4 == 0, n <= 16384.
-__global__ __launch_bounds__(256) void k_gather_reversed_lds(const float *__restrict__ H, int n, int ld,
+__global__ __launch_bounds__(256) void k_gather_reversed_lds(const PtrTable hs, int n, int ld,
                                                              const long long *__restrict__ order,
                                                              const float *__restrict__ scal, double *__restrict__ A) {
     extern __shared__ __attribute__((aligned(16))) float srow[];
+    const float *__restrict__ H = hs.p[blockIdx.z];
+    order += (size_t)n * blockIdx.z;
+    scal += 64 * blockIdx.z;
+    A += (size_t)ld * ld * blockIdx.z;
     const double add = (double)scal[1];
     const int t = threadIdx.x, n4 = n >> 2;
     for (int i = blockIdx.x; i < ld; i += gridDim.x) {
@@ -278,6 +294,12 @@ __global__ __launch_bounds__(256) void k_pivot_keys(const int *__restrict__ piv,
 
 using namespace slk;
 
+static inline PtrTable one_h(const float *H) {
+    PtrTable t;
+    for (int b = 0; b < 64; ++b) t.p[b] = b == 0 ? H : nullptr;
+    return t;
+}
+
 extern "C" {
 
 int slk_factor_ld(int n) { return (n + 63) / 64 * 64; }
@@ -362,8 +384,8 @@ int slk_inverse_diag_keys(const double *U, const float *H, int n, float damp, in
         return SLK_E_WS;
     }
     hipStream_t s = as_stream(stream);
-    SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
-    SLK_RUN("order_keys", 0, 12.0 * n, s, k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, nullptr, scal, tmp));
+    SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(one_h(H), n, n, scal));
+    SLK_RUN("order_keys", 0, 12.0 * n, s, k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(one_h(H), n, damp, nullptr, scal, tmp));
     SLK_RUN("inverse_diag_keys", 0, 4.0 * n * n, s,
             k_inverse_diag_keys<<<(n + 31) / 32, 256, 0, s>>>(U, H, scal, n, combined, keys));
     return SLK_OK;
@@ -386,8 +408,8 @@ int slk_pivot_keys(const float *H, int n, float damp, double *keys, void *worksp
     }
     hipStream_t s = as_stream(stream);
     const int nb = (n + 255) / 256;
-    SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
-    SLK_RUN("order_keys", 0, 12.0 * n, s, k_order_keys<<<nb, 256, 0, s>>>(H, n, damp, nullptr, scal, tmp));  // scal[1] = damping term
+    SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(one_h(H), n, n, scal));
+    SLK_RUN("order_keys", 0, 12.0 * n, s, k_order_keys<<<nb, 256, 0, s>>>(one_h(H), n, damp, nullptr, scal, tmp));  // scal[1] = damping term
     SLK_RUN("pivot_init", 0, 16.0 * n, s, k_pivot_init<<<nb, 256, 0, s>>>(H, n, scal, diag, pos));
     for (int k = 0; k < n; ++k) {
         SLK_RUN_W("pivot_select", 0, 12.0 * (n - k), 1, s, k_pivot_select<<<1, 256, 0, s>>>(diag, pos, n, k, piv, dpiv));
@@ -402,7 +424,47 @@ int slk_pivot_keys(const float *H, int n, float damp, double *keys, void *worksp
 int slk_diag_mean(const float *H, int n, float *out, void *, size_t, slk_stream_t stream) {
     SLK_REQUIRE(H && out && n > 0, "bad arguments");
     hipStream_t s = as_stream(stream);
-    SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, out));
+    SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(one_h(H), n, n, out));
+    return SLK_OK;
+}
+
+static int hessian_prepare_impl(const PtrTable &hs, int batch, int n, float damp, int order_mode, const float *miss,
+                                long long *order_out, double *A, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+    Arena ws(workspace, ws_bytes);
+    float *scal = ws.take<float>(64 * (size_t)batch);
+    double *keys = ws.take<double>((size_t)n * batch);
+    int *rank = ws.take<int>((size_t)n * batch);
+    if (!scal || !keys || !rank) {
+        set_error("workspace too small");
+        return SLK_E_WS;
+    }
+    hipStream_t s = as_stream(stream);
+    const int ld = slk_factor_ld(n);
+    const unsigned B = (unsigned)batch;
+    bool aligned = true;
+    for (int b = 0; b < batch; ++b) aligned = aligned && (uintptr_t)hs.p[b] % 16 == 0;
+    SLK_RUN_W("diag_mean", 0, 4.0 * n * batch, batch, s, k_diag_mean<<<dim3(1, 1, B), 256, 0, s>>>(hs, n, n, scal));
+    const bool weighted = order_mode == SLK_ORDER_ERR || order_mode == SLK_ORDER_SQERR;
+    SLK_RUN("order_keys", 0, 12.0 * n * batch, s,
+            k_order_keys<<<dim3((n + 255) / 256, 1, B), 256, 0, s>>>(hs, n, damp, weighted ? miss : nullptr, scal, keys));
+    if (order_mode == SLK_ORDER_KEYS)  // caller-supplied float64 sort keys (ascending)
+        copy_async(keys, miss, sizeof(double) * (size_t)n, s);
+    const int identity = order_mode == SLK_ORDER_NONE;
+    if (!identity) {
+        zero_async(rank, sizeof(int) * (size_t)n * batch, s);
+        const int slices = 16, slice = (n + slices - 1) / slices;
+        SLK_RUN("rank_partial", 0, 16.0 * n * batch, s,
+                k_rank_partial<<<dim3((n + 255) / 256, slices, B), 256, 0, s>>>(keys, n, slice, rank));
+    }
+    SLK_RUN("rank_scatter", 0, 12.0 * n * batch, s, k_rank_scatter<<<dim3((n + 255) / 256, 1, B), 256, 0, s>>>(rank, n, identity, order_out));
+    if (n % 4 == 0 && n <= 16384 && aligned) {
+        SLK_LDS_OPT_IN(k_gather_reversed_lds, 16384 * 4);
+        SLK_RUN("gather_reversed", 0, (4.0 * n * n + 4.0 * ld * ld) * batch, s,
+                k_gather_reversed_lds<<<dim3(ld < 2048 ? ld : 2048, 1, B), 256, (size_t)n * 4, s>>>(hs, n, ld, order_out, scal, A));
+    } else {
+        SLK_RUN("gather_reversed", 0, (2.0 * n * n + 8.0 * ld * ld) * batch, s,
+                k_gather_reversed<<<dim3(ld < 2048 ? ld : 2048, 1, B), 256, 0, s>>>(hs, n, ld, order_out, scal, A));
+    }
     return SLK_OK;
 }
 
@@ -413,38 +475,18 @@ int slk_hessian_prepare(const float *H, int n, float damp, int order_mode, const
     SLK_REQUIRE(order_mode >= SLK_ORDER_NONE && order_mode <= SLK_ORDER_KEYS, "Invalid act_order value %d",
                 order_mode);
     SLK_REQUIRE(order_mode < SLK_ORDER_ERR || miss, "err/sqerr/keys orders need their input vector");
-    Arena ws(workspace, ws_bytes);
-    float *scal = ws.take<float>(64);
-    double *keys = ws.take<double>((size_t)n);
-    int *rank = ws.take<int>((size_t)n);
-    if (!scal || !keys || !rank) {
-        set_error("workspace too small");
-        return SLK_E_WS;
-    }
-    hipStream_t s = as_stream(stream);
-    const int ld = slk_factor_ld(n);
-    SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(H, n, n, scal));
-    const bool weighted = order_mode == SLK_ORDER_ERR || order_mode == SLK_ORDER_SQERR;
-    SLK_RUN("order_keys", 0, 12.0 * n, s,
-            k_order_keys<<<(n + 255) / 256, 256, 0, s>>>(H, n, damp, weighted ? miss : nullptr, scal, keys));
-    if (order_mode == SLK_ORDER_KEYS)  // caller-supplied float64 sort keys (ascending)
-        copy_async(keys, miss, sizeof(double) * (size_t)n, s);
-    const int identity = order_mode == SLK_ORDER_NONE;
-    if (!identity) {
-        zero_async(rank, sizeof(int) * (size_t)n, s);
-        const int slices = 16, slice = (n + slices - 1) / slices;
-        SLK_RUN("rank_partial", 0, 16.0 * n, s, k_rank_partial<<<dim3((n + 255) / 256, slices), 256, 0, s>>>(keys, n, slice, rank));
-    }
-    SLK_RUN("rank_scatter", 0, 12.0 * n, s, k_rank_scatter<<<(n + 255) / 256, 256, 0, s>>>(rank, n, identity, order_out));
-    if (n % 4 == 0 && n <= 16384 && (uintptr_t)H % 16 == 0) {
-        SLK_LDS_OPT_IN(k_gather_reversed_lds, 16384 * 4);
-        SLK_RUN("gather_reversed", 0, 4.0 * n * n + 4.0 * ld * ld, s,
-                k_gather_reversed_lds<<<ld < 2048 ? ld : 2048, 256, (size_t)n * 4, s>>>(H, n, ld, order_out, scal, A));
-    } else {
-        SLK_RUN("gather_reversed", 0, 2.0 * n * n + 8.0 * ld * ld, s,
-                k_gather_reversed<<<ld < 2048 ? ld : 2048, 256, 0, s>>>(H, n, ld, order_out, scal, A));
-    }
-    return SLK_OK;
+    return hessian_prepare_impl(one_h(H), 1, n, damp, order_mode, miss, order_out, A, workspace, ws_bytes, stream);
+}
+
+int slk_hessian_prepare_batch(const float *const *H, int batch, int n, float damp, int order_mode,
+                              long long *order_out, double *A, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+    SLK_REQUIRE(H && order_out && A && n > 0, "bad arguments");
+    SLK_REQUIRE(batch >= 1 && batch <= 64, "batch must be 1..64");
+    SLK_REQUIRE(order_mode == SLK_ORDER_NONE || order_mode == SLK_ORDER_DIAG, "the batch form takes the orders none and diag");
+    PtrTable hs;
+    for (int b = 0; b < 64; ++b) hs.p[b] = b < batch ? H[b] : nullptr;
+    for (int b = 0; b < batch; ++b) SLK_REQUIRE(H[b], "null Hessian in the batch");
+    return hessian_prepare_impl(hs, batch, n, damp, order_mode, nullptr, order_out, A, workspace, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -197,11 +197,8 @@ class HipBackend:
         from . import _device as dev
         from . import _lib
 
-        eng = self.engine
         B, n = len(round_layers), round_layers[0]["H"].shape[0]
         device = round_layers[0]["W"].device
-        rows = hi - lo
-        Rp = (rows + 127) // 128 * 128  # the batch entry points want whole 128-row tiles per layer (96 rows at 768 / 8)
         # the stacked factors live in a buffer per stream, zeroed once: only the upper triangles are rewritten each round
         # (use on one stream is ordered; rounds on other streams have buffers of their own)
         if not hasattr(self, "_ustacks"):
@@ -215,6 +212,40 @@ class HipBackend:
         for b, payload in enumerate(payloads):
             _lib.check(_lib.lib.slk_factor_unpack_upper(dev.ptr(payload), n, U[b].data_ptr(), order[b].data_ptr(),
                                                         info[b:b + 1].data_ptr(), dev.stream_handle()))
+        known = None
+        if self.with_error:
+            mark = self.payload_words(n) - 1
+            # (every rank runs the same backend settings, so with_error here means the roots packed real verdicts)
+            known = torch.stack([p[mark] for p in payloads]).to(torch.int32)
+        return self._run_stacked(round_layers, lo, hi, order, U, info, known)
+
+    # -- one rank, small layers: a round of same-shaped layers is factored AND looped in launches that cover them all
+    local_batch = 8          # layers per such round (1: off)
+    local_batch_cols = 1536  # widest layer that takes this route
+
+    def wants_local_batch(self, layer):
+        """Small layers are bound by the host's launch rate (a 768-column layer is ~50 launches of microseconds each):
+        batched by shape, a round of them costs the launches of one.  Wide layers fill the chip alone and overlap
+        better on separate streams (factor chains beside loops)."""
+        return (self.local_batch > 1 and layer["H"].shape[0] <= self.local_batch_cols
+                and self.engine.order_mode_code(self.act_order) in (0, 1))
+
+    def run_round_local(self, round_layers):
+        """All rows of a round's layers on this rank: batched factorisation (engine.factorize_batch), then the
+        stacked loop / local search / error of run_round."""
+        eng = self.engine
+        n = round_layers[0]["H"].shape[0]
+        order, U, info = eng.factorize_batch([lay["H"] for lay in round_layers], n, self.damp, eng.order_mode_code(self.act_order))
+        return self._run_stacked(round_layers, 0, round_layers[0]["W"].shape[0], order, U, info, None)
+
+    def _run_stacked(self, round_layers, lo, hi, order, U, info, known):
+        """Rows [lo, hi) of every layer of the round through ONE loop and ONE error evaluation, from stacked factors
+        order (B, n), U (B, n, n), info (B,); known: the symmetry verdicts of the Hessians, or None (checked here)."""
+        eng = self.engine
+        B, n = len(round_layers), round_layers[0]["H"].shape[0]
+        device = round_layers[0]["W"].device
+        rows = hi - lo
+        Rp = (rows + 127) // 128 * 128  # the batch entry points want whole 128-row tiles per layer (96 rows at 768 / 8)
         scaled = round_layers[0].get("scale") is not None
         if Rp == rows:
             W = torch.stack([lay["W"][lo:hi] for lay in round_layers])
@@ -242,9 +273,6 @@ class HipBackend:
             Q, idx = eng.run_loop_batch(W, sc, order, U, cb, 32, 8, unscale=sc is not None)
         err = None
         if self.with_error:
-            mark = self.payload_words(n) - 1
-            # (every rank runs the same backend settings, so with_error here means the roots packed real verdicts)
-            known = torch.stack([p[mark] for p in payloads]).to(torch.int32)
             err = eng.row_errors_batch(W, Q, [lay["H"] for lay in round_layers], known)
         return [dict(Q=Q[b, :rows], idx=idx[b, :rows], row_err=None if err is None else err[b, :rows], rows=(lo, hi),
                      info=info[b:b + 1]) for b in range(B)]
@@ -274,7 +302,46 @@ def _all_gather_words(payload, size):
     return outs, dist.all_gather(outs, payload, async_op=True)
 
 
-def quantize_stream(layers, backend, comm_device=None, join=True):
+def _quantize_stream_local(layers, small, backend, join):
+    """One rank, a stream with small layers in it (quantize_stream): the small ones in batched rounds by shape, one round
+    after the other on alternating streams (a round is a chain of short launches: two or three in flight fill the gaps);
+    the rest through the usual route."""
+    n_layers = len(layers)
+    out = [None] * n_layers
+    fstreams, _, lstreams = backend.streams()
+    pool = (fstreams + lstreams) if fstreams is not None else [None]
+    here = torch.cuda.current_stream() if pool[0] is not None else None
+    rounds, _ = plan_rounds([layers[l] for l in small], backend.local_batch)
+    for st in pool:
+        if st is not None:
+            st.wait_stream(here)
+    for i, members in enumerate(rounds):
+        st = pool[i % len(pool)]
+        idxs = [small[m] for m in members]
+        with (torch.cuda.stream(st) if st is not None else _NullCtx()):
+            if len(idxs) == 1:
+                lay = layers[idxs[0]]
+                fac = backend.factorize(lay)
+                shards = [dict(backend.run_rows(lay, 0, lay["W"].shape[0], fac), info=fac[2])]
+            else:
+                shards = backend.run_round_local([layers[l] for l in idxs])
+        for l, shard in zip(idxs, shards):
+            out[l] = shard
+            if here is not None:
+                for t in shard.values():
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(here)
+    rest = [l for l in range(n_layers) if l not in set(small)]
+    if rest:
+        for l, shard in zip(rest, quantize_stream([layers[l] for l in rest], backend, join=join, _local=False)):
+            out[l] = shard
+    if join and here is not None:
+        for st in pool:
+            here.wait_stream(st)
+    return out
+
+
+def quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
     """Quantize `layers` (list of dicts with W (R, n), H (n, n), optional scale (R,)) across the ranks.
 
     Returns, per layer, this rank's shard: dict(Q, idx, row_err, rows=(lo, hi), info).
@@ -301,6 +368,11 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
     """
     rank, size = world()
     n_layers = len(layers)
+    if size == 1 and not always_exchange and _local and hasattr(backend, "run_round_local"):
+        # one rank: small layers go in rounds of one shape, factored and looped in launches that cover the round
+        small = [l for l in range(n_layers) if backend.wants_local_batch(layers[l])]
+        if len(small) > 1:
+            return _quantize_stream_local(layers, small, backend, join)
     fstreams, cstream, lstreams = backend.streams() if hasattr(backend, "streams") else (None, None, None)
     side = fstreams is not None
     here = torch.cuda.current_stream() if side else None

@@ -96,6 +96,28 @@ def factorize(H, n, damp, mode, miss=None, keep=None):
     return order, U, info
 
 
+def factorize_batch(Hs, n, damp, mode):
+    """Damping + order + float64 factor of B same-sized float32 device Hessians in launches that cover them all
+    (slk_hessian_prepare_batch / slk_chol_inverse_upper_batch).  Returns order (B, n), U (B, n, n), info (B,):
+    the results of B calls of factorize."""
+    import ctypes
+
+    B = len(Hs)
+    device = Hs[0].device
+    assert all(H.shape == (n, n) and H.is_contiguous() and H.dtype == torch.float32 for H in Hs)
+    ws, ws_bytes = dev.scratch(_lib.lib.slk_factor_workspace_bytes_batch(B, n), "factor_batch")
+    s = dev.stream_handle()
+    ld = _lib.lib.slk_factor_ld(n)
+    order = torch.empty((B, n), dtype=torch.int64, device=device)
+    A = torch.empty(B * ld * ld, dtype=torch.float64, device=device)
+    U = torch.empty((B, n, n), dtype=torch.float64, device=device)
+    info = torch.empty(B, dtype=torch.int32, device=device)
+    ptrs = (ctypes.c_void_p * B)(*[dev.ptr(H) for H in Hs])
+    _lib.check(_lib.lib.slk_hessian_prepare_batch(ptrs, B, n, float(damp), mode, dev.ptr(order), dev.ptr(A), dev.ptr(ws), ws_bytes, s))
+    _lib.check(_lib.lib.slk_chol_inverse_upper_batch(dev.ptr(A), B, n, dev.ptr(U), dev.ptr(info), dev.ptr(ws), ws_bytes, s))
+    return order, U, info
+
+
 def factorize_order_only(H, n, mode, miss=None):
     """Column order of an already damped float32 Hessian (compute_hessian_order, obq.py:58-86)."""
     ws, ws_bytes = dev.workspace(0, n)

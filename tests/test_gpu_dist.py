@@ -87,3 +87,43 @@ def test_two_ranks_one_gpu_match_single_process():
         assert np.array_equal(np.concatenate([q0, q1]), single[l]["Q"].cpu().numpy())
         want = float(single[l]["row_err"].double().sum() / R)
         assert abs(got[0][2][l] - want) <= 1e-6 * abs(want)
+
+
+@pytest.mark.parametrize("moves", [0, 5])
+def test_small_layers_in_batched_rounds_on_one_rank(moves):
+    """One rank, a model-order stream of small layers (shapes alternate, one shape ragged): sleekit_amd.dist takes them in
+    rounds of one shape, factored by slk_*_batch and looped as one stack -- every layer bit-equal to its own
+    engine.quantize_layer, the factors bit-equal to engine.factorize."""
+    from sleekit_amd import _lib, codebook, engine, synth
+    from sleekit_amd import dist as sdist
+
+    dev = torch.device("cuda", 0)
+    cb = codebook.UniformCodebook(8, -1, 1)
+    shapes = [(256, 192), (100, 320), (128, 1100), (256, 192), (100, 320), (256, 192), (64, 2048), (100, 320)]
+    layers = []
+    for i, (R, n) in enumerate(shapes):
+        L = synth.make_layer(R, n, 3100 + i)
+        layers.append({k: torch.from_numpy(L[k]).to(dev) for k in ("W", "H", "scale")})
+    be = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True)
+    calls = {"local": 0}
+    run_local = be.run_round_local
+    be.run_round_local = lambda members: (calls.__setitem__("local", calls["local"] + 1), run_local(members))[1]
+    shards = sdist.quantize_stream(layers, be)
+    torch.cuda.synchronize()
+    assert calls["local"] == 2  # (256, 192) x 3 and (100, 320) x 3; 1100 and 2048 columns alone
+    for lay, sh in zip(layers, shards):
+        res = engine.quantize_layer(lay["W"], lay["H"], cb, lay["scale"], nb_ls_moves=moves)
+        err = engine.row_errors(lay["W"], res.Q, lay["H"])
+        assert torch.equal(sh["Q"], res.Q) and torch.equal(sh["idx"], res.idx) and int(sh["info"].item()) == 0
+        np.testing.assert_allclose(sh["row_err"].cpu().numpy(), err.cpu().numpy(), rtol=1e-5)
+    # the batched factorisation alone, against the single-layer one: same order, same U bit for bit, not-PD reported per layer
+    Hs = [layers[i]["H"] for i in (0, 3, 5)]
+    Hs[1] = Hs[1].clone()
+    Hs[1][7, 7] = -1.0
+    order, U, info = engine.factorize_batch(Hs, 192, 0.01, _lib.ORDER_DIAG)
+    for b, H in enumerate(Hs):
+        o1, u1, i1 = engine.factorize(H, 192, 0.01, _lib.ORDER_DIAG)
+        assert torch.equal(order[b], o1) and int(info[b].item()) == int(i1.item())
+        if b != 1:
+            assert torch.equal(U[b], u1) and int(i1.item()) == 0
+    assert int(info[1].item()) > 0

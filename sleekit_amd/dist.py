@@ -102,6 +102,10 @@ class HipBackend:
 
         self.engine, self.quantizer, self.overlap = engine, quantizer, overlap
         self.act_order, self.damp, self.moves, self.with_error = act_order, damp, nb_ls_moves, with_error
+        import os
+
+        self.local_batch = int(os.environ.get("SLK_LOCAL_BATCH", self.local_batch))            # (measurement knobs)
+        self.local_batch_cols = int(os.environ.get("SLK_LOCAL_BATCH_COLS", self.local_batch_cols))
 
     def streams(self):
         """(factor streams, comm stream, loop streams), created once; (None, None, None) = everything in order."""
@@ -221,14 +225,16 @@ class HipBackend:
 
     # -- one rank, small layers: a round of same-shaped layers is factored AND looped in launches that cover them all
     local_batch = 8          # layers per such round (1: off)
-    local_batch_cols = 1536  # widest layer that takes this route
+    local_batch_cols = 1536  # widest layer that takes this route whatever its rows (up to twice that with <= 1024 rows)
 
     def wants_local_batch(self, layer):
         """Small layers are bound by the host's launch rate (a 768-column layer is ~50 launches of microseconds each):
-        batched by shape, a round of them costs the launches of one.  Wide layers fill the chip alone and overlap
-        better on separate streams (factor chains beside loops)."""
-        return (self.local_batch > 1 and layer["H"].shape[0] <= self.local_batch_cols
-                and self.engine.order_mode_code(self.act_order) in (0, 1))
+        batched by shape, a round of them costs the launches of one (OPT-125M, 72 layers: 47.8 -> 17.6 ms; rounds of 16
+        or 4096-column layers in them changed nothing).  Big layers fill the chip alone and overlap better on separate
+        streams (factor chains beside loops)."""
+        R, n = layer["W"].shape
+        small = n <= self.local_batch_cols or (n <= 2 * self.local_batch_cols and R <= 1024)
+        return self.local_batch > 1 and small and self.engine.order_mode_code(self.act_order) in (0, 1)
 
     def run_round_local(self, round_layers):
         """All rows of a round's layers on this rank: batched factorisation (engine.factorize_batch), then the

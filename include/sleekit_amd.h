@@ -61,7 +61,7 @@ typedef void *slk_stream_t;
 /* Library / device ---------------------------------------------------------
  * slk_abi_version: 4.  History: 2 = every quantizing entry takes (levels, lo, hi, table); 3 adds the batch forms
  * (slk_gptq_quantize_batch, slk_row_errors_batch, slk_workspace_bytes_batch) and slk_symmetry_flag; 4 adds the
- * `trace` argument of slk_local_search, slk_set_option / slk_get_option and the batched factorisation
+ * `trace` and `gains` arguments of slk_local_search, slk_set_option / slk_get_option and the batched factorisation
  * (slk_hessian_prepare_batch, slk_chol_inverse_upper_batch, slk_factor_workspace_bytes_batch).                 */
 int slk_abi_version(void);
 const char *slk_last_error(void);
@@ -219,10 +219,15 @@ int slk_symmetry_flag(const float *H, int n, int *flag, slk_stream_t stream);
  *     pairwise order, so that from equal initial gains the moves are the reference's bit for bit.
  *     trace (may be NULL): R x moves int32, the moves taken -- 2 * column + (1: up, 0: down), or -1 from
  *     the first move on at which the row had nothing left to gain (parity tests compare it with the
- *     reference's sequence of moves to find where, if anywhere, a near-tie fell the other way).      */
+ *     reference's sequence of moves to find where, if anywhere, a near-tie fell the other way).
+ *     gains / gains_mode: the state of the reference's stateful LocalSearchQuantizer (obq.py:234-346) between calls --
+ *     R x 2 x n float32, per row the n up-gains then the n down-gains.  gains_mode 0: none (gains may be NULL);
+ *     1: the initial gains are built from (W - Q) H as usual, and the gains after the moves are stored (moves == 0
+ *     gives the constructor's state, obq.py:259-262); 2: the gains are LOADED, the moves made, the gains stored --
+ *     k calls with moves = 1 are then one call with moves = k, bit for bit, like k calls of do_move().       */
 int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
-                     double hi, const float *table, int moves, uint8_t *idx, int *trace, void *workspace,
-                     size_t ws_bytes, slk_stream_t stream);
+                     double hi, const float *table, int moves, uint8_t *idx, int *trace, float *gains,
+                     int gains_mode, void *workspace, size_t ws_bytes, slk_stream_t stream);
 
 /* Scale selection: the callers' pre-step -------------------------- */
 /* compute_non_saturating_scaling (sleekit/scaling.py:44-55): scale[r] = max(max_r / hi_code,

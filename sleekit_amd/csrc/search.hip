@@ -53,7 +53,8 @@ template <int EPT>
 __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ W, float *__restrict__ Q,
                                                       const float *__restrict__ H, const float *__restrict__ G,
                                                       const float *__restrict__ hdiag, int R, int n, Grid g,
-                                                      int moves, uint8_t *__restrict__ idx, int *__restrict__ trace) {
+                                                      int moves, uint8_t *__restrict__ idx, int *__restrict__ trace,
+                                                      float *__restrict__ gains, int gains_mode) {
     __shared__ Best red_up[4], red_dn[4];
     __shared__ HeapSum plan;
     extern __shared__ float terms[];  // heap_sum_floats(n): the products of the interaction sum, staged for NumPy's order
@@ -71,12 +72,19 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         if (j < n) {
             w[e] = W[base + j];
             q[e] = Q[base + j];
-            const float gj = G[base + j], hjj = hdiag[j];
-            const float du = cand_up(q[e], g) - q[e];
-            const float dd = cand_down(q[e], g) - q[e];
-            // -D^2 * H_jj - 2 * (delta @ H)_j * D  with (delta @ H)_j = -G_j     (obq.py:229-231)
-            gu[e] = (-(du * du)) * hjj + (2.0f * gj) * du;
-            gd[e] = (-(dd * dd)) * hjj + (2.0f * gj) * dd;
+            if (gains_mode == 2) {
+                // carried over from an earlier call (the stateful LocalSearchQuantizer, obq.py:234-346): the gains as
+                // the reference holds them between two do_move() calls, incrementally updated, not rebuilt
+                gu[e] = gains[2 * base + j];
+                gd[e] = gains[2 * base + n + j];
+            } else {
+                const float gj = G[base + j], hjj = hdiag[j];
+                const float du = cand_up(q[e], g) - q[e];
+                const float dd = cand_down(q[e], g) - q[e];
+                // -D^2 * H_jj - 2 * (delta @ H)_j * D  with (delta @ H)_j = -G_j     (obq.py:229-231)
+                gu[e] = (-(du * du)) * hjj + (2.0f * gj) * du;
+                gd[e] = (-(dd * dd)) * hjj + (2.0f * gj) * dd;
+            }
         } else {
             w[e] = q[e] = 0.0f;
             gu[e] = gd[e] = NEG;
@@ -175,6 +183,10 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         if (j < n) {
             Q[base + j] = q[e];
             if (idx) idx[base + j] = (uint8_t)cb_index(q[e], g);
+            if (gains_mode) {
+                gains[2 * base + j] = gu[e];
+                gains[2 * base + n + j] = gd[e];
+            }
         }
     }
 }
@@ -184,12 +196,13 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 using namespace slk;
 
 extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
-                                double hi, const float *table, int moves, uint8_t *idx, int *trace, void *workspace,
-                                size_t ws_bytes, slk_stream_t stream) {
+                                double hi, const float *table, int moves, uint8_t *idx, int *trace, float *gains,
+                                int gains_mode, void *workspace, size_t ws_bytes, slk_stream_t stream) {
     SLK_REQUIRE(W && Q && H && R > 0 && n > 0 && moves >= 0, "bad arguments");
     SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
     SLK_REQUIRE(idx == nullptr || levels <= 256, "uint8 indices need levels <= 256");
     SLK_REQUIRE(n <= 256 * 64, "local search supports n <= 16384");
+    SLK_REQUIRE(gains_mode >= 0 && gains_mode <= 2 && (gains_mode == 0 || gains), "gains_mode 1 / 2 needs the gains buffer");
     Arena ws(workspace, ws_bytes);
     float *G = ws.take<float>((size_t)R * n);
     float *row_err = ws.take<float>((size_t)R);
@@ -199,18 +212,20 @@ extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R,
         return SLK_E_WS;
     }
     const size_t used = align_up(ws.used, 256);
-    int rc = slk_row_errors(W, Q, H, R, n, row_err, G, static_cast<char *>(workspace) + used, ws_bytes - used, stream);
-    if (rc != SLK_OK) return rc;
+    if (gains_mode != 2) {  // (carried gains: no initial product)
+        int rc = slk_row_errors(W, Q, H, R, n, row_err, G, static_cast<char *>(workspace) + used, ws_bytes - used, stream);
+        if (rc != SLK_OK) return rc;
+    }
     hipStream_t s = as_stream(stream);
     SLK_RUN("extract_diag", 0, 8.0 * n, s, k_extract_diag<<<(n + 255) / 256, 256, 0, s>>>(H, n, hdiag));
     const Grid g = make_grid(levels, lo, hi, table);
     const int ept = (n + 255) / 256;
     const size_t lds = (size_t)(n + 8 * (n / 128) + 8) * sizeof(float);  // heap_sum_floats(n)
-#define SLK_LS(E)                                                                                          \
-    do {                                                                                                   \
-        SLK_LDS_OPT_IN(k_local_search<E>, lds);                                                            \
-        SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,              \
-                k_local_search<E><<<R, 256, lds, s>>>(W, Q, H, G, hdiag, R, n, g, moves, idx, trace));     \
+#define SLK_LS(E)                                                                                                   \
+    do {                                                                                                            \
+        SLK_LDS_OPT_IN(k_local_search<E>, lds);                                                                     \
+        SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                       \
+                k_local_search<E><<<R, 256, lds, s>>>(W, Q, H, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode)); \
     } while (0)
     if (ept <= 4) SLK_LS(4);
     else if (ept <= 8) SLK_LS(8);

@@ -198,17 +198,18 @@ def symmetry_flag(H):
     return flag
 
 
-def local_search(W, Q, H, cb_abi, moves, idx=None, want_trace=False):
+def local_search(W, Q, H, cb_abi, moves, idx=None, want_trace=False, gains=None, gains_mode=0):
     """In place on Q (and idx).  want_trace: returns the (R, moves) int32 record of the moves taken
-    (2 * column + up, -1 = none), see slk_local_search."""
+    (2 * column + up, -1 = none); gains / gains_mode: the carried state of a stateful search (slk_local_search)."""
     R, n = W.shape
     levels, lo, hi, table = cb_abi
     ws, ws_bytes = dev.workspace(R, n)
     trace = torch.empty((R, int(moves)), dtype=torch.int32, device=W.device) if want_trace else None
+    assert gains is None or (gains.shape == (R, 2, n) and gains.dtype == torch.float32 and gains.is_contiguous())
     _lib.check(
         _lib.lib.slk_local_search(
             dev.ptr(W), dev.ptr(Q), dev.ptr(H), R, n, levels, lo, hi, dev.ptr(table), int(moves), dev.ptr(idx), dev.ptr(trace),
-            dev.ptr(ws), ws_bytes, dev.stream_handle(),
+            dev.ptr(gains), int(gains_mode), dev.ptr(ws), ws_bytes, dev.stream_handle(),
         )
     )
     return trace

@@ -166,11 +166,13 @@ def quantize_local_search(W, Q, H, quantizer, nb_moves):
 
 
 class LocalSearchQuantizer:
-    """Stateful wrapper with the reference's interface (sleekit/obq.py:234-346).
+    """Stateful search with the reference's interface (sleekit/obq.py:234-346).
 
-    `do_move()` advances one move per row.  The device kernel rebuilds the gains from the
-    current Q on each call instead of carrying them, so `gain_up` / `gain_down` are
-    computed on demand.
+    The gains live on the device between calls (slk_local_search, gains_mode): the constructor builds them from
+    (W - Q) H like obq.py:259-262, `do_move()` loads them, makes one move per row and stores them -- the reference's
+    incremental updates, so k calls of `do_move()` are `quantize_local_search(..., k)` bit for bit and `gain_up` /
+    `gain_down` are the arrays the reference would hold.  `err` is recomputed from Q when asked (the reference
+    carries it by subtracting the gains of the moves).
     """
 
     def __init__(self, W, Q, H, quantizer):
@@ -184,6 +186,9 @@ class LocalSearchQuantizer:
         self.quantizer = quantizer
         self._W, self._H = dev.to_device(W), dev.to_device(H)
         self._Q = dev.to_device(Q).clone()
+        R, n = self._W.shape
+        self._gains = torch.empty((R, 2, n), dtype=torch.float32, device=self._W.device)
+        engine.local_search(self._W, self._Q, self._H, self._cb, 0, gains=self._gains, gains_mode=1)
 
     @property
     def nchannels(self):
@@ -215,11 +220,11 @@ class LocalSearchQuantizer:
 
     @property
     def gain_up(self):
-        return dev.like_input(compute_gain(self._W, self._Q, self._H, self.quantizer.quantize_up(self._Q)), self._like)
+        return dev.like_input(self._gains[:, 0].contiguous(), self._like)
 
     @property
     def gain_down(self):
-        return dev.like_input(compute_gain(self._W, self._Q, self._H, self.quantizer.quantize_down(self._Q)), self._like)
+        return dev.like_input(self._gains[:, 1].contiguous(), self._like)
 
     def do_move(self):
-        engine.local_search(self._W, self._Q, self._H, self._cb, 1)
+        engine.local_search(self._W, self._Q, self._H, self._cb, 1, gains=self._gains, gains_mode=2)

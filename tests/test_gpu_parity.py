@@ -561,6 +561,18 @@ def test_local_search_standalone(amd):
         got = amd.obq.quantize_local_search(Ws, Q0, L["H"], cb, moves)
         assert np.array_equal(got, want), moves
     assert amd.obq.quantize_local_search(Ws, Q0, L["H"], cb, 0) is Q0
+    # the stateful class (obq.py:234-346): k calls of do_move() == quantize_local_search(k), bit for bit, and the gains it
+    # holds after them are the oracle's incrementally updated ones wherever the moves agree (they do on this layer)
+    ls = amd.obq.LocalSearchQuantizer(Ws, Q0, L["H"], cb)
+    state = obq_ref._SearchState(Ws, Q0, L["H"], g)
+    for k in range(1, 8):
+        ls.do_move()
+        state.move()
+        assert np.array_equal(ls.Q, amd.obq.quantize_local_search(Ws, Q0, L["H"], cb, k)), k
+        assert np.array_equal(ls.Q, state.Q), k
+    for got, want in ((ls.gain_up, state.gain[+1]), (ls.gain_down, state.gain[-1])):
+        unit = 2.0 ** -24 * 2.0 * (2.0 / 7.0) * obq_ref.gain_noise_scale(Ws, Q0, L["H"])
+        assert (np.abs(got.astype(np.float64) - want) <= 8.0 * unit + 1e-12).all()
     # gains (obq.py:220-231): -D^2 H_jj - 2 (delta @ H)_j D.  The GEMM's summation order is the BLAS's own, so the
     # comparison is per entry against the rounding of ITS terms: 2 |D| (|delta| @ |H|)_j + D^2 H_jj, a few roundings
     for cand in (g.up(Q0), g.down(Q0)):

@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsleekit_amd.so")
+LIB_PATH = os.environ.get("SLK_LIB_PATH") or os.path.join(_HERE, "libsleekit_amd.so")  # (override: A/B builds in tools/)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -26,17 +26,20 @@ constexpr int OUTER = 256;
 constexpr int TP = 66;  // pitch of the 64 x 64 LDS tiles: MFMA operand reads walk banks 4 row + 2 k
 
 struct PanelSmem {
-    double t[PANEL][TP];  // diagonal tile -> L11 (lower)
-    double x[PANEL][TP];  // inv(L11)
-    double rdiag[PANEL];  // 1 / L11[j][j]
-    Tile64Smem mm;
+    double t[PANEL][TP];    // diagonal tile -> L11 (lower)
+    double x[PANEL][TP];    // inv(L11)
+    double a21[PANEL][TP];  // this workgroup's tile of A21, staged while the diagonal tile is being factored
+    double rdiag[PANEL];    // 1 / L11[j][j]
 };
 
 // 1/sqrt(d) to double precision: hardware estimate + two Newton steps (3 dependent ops each).
+#ifndef NEWTON_STEPS
+#define NEWTON_STEPS 2
+#endif
 __device__ __forceinline__ double rsqrt_newton(double d) {
     double y = __builtin_amdgcn_rsq(d);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NEWTON_STEPS; ++it) {
         const double e = __builtin_fma(-(d * y), y, 1.0);
         y = __builtin_fma(0.5 * y, e, y);
     }
@@ -104,12 +107,47 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
 
+    // this workgroup's tile of A21, fetched NOW: it does not depend on the factorisation, and loaded only when the
+    // final product starts its trip to memory (~1.5 us) would sit on the critical path of every panel
+    double a21[2][8];
+    if (blockIdx.x > 0) {
+        const double *pa = A + (size_t)(k0 + PANEL * blockIdx.x + (t >> 2)) * ld + k0 + (t & 3) * 8;
+        load8d<true>(pa, a21[0]);
+        load8d<true>(pa + 32, a21[1]);
+    }
     for (int e = t; e < PANEL * PANEL; e += 256) {
         const int r = e >> 6, c = e & 63;
         sm.t[r][c] = (c <= r) ? A[(size_t)(k0 + r) * ld + k0 + c] : 0.0;
         sm.x[r][c] = 0.0;
     }
     __syncthreads();
+
+    // inverse of the 16 x 16 diagonal block of strip kb: lane c < 16 owns column c of X[kb, kb] (wave 3 runs it while
+    // wave 0 is in the NEXT strip's chain: the block and its reciprocal diagonal are final by then, and nothing else
+    // touches them)
+    auto diag_inverse = [&](int kb) {
+        const int c0 = 16 * kb, c = lane & 15;
+        double xv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int u = 0; u < i; ++u) s = __builtin_fma(sm.t[c0 + i][c0 + u], xv[u], s);  // broadcast reads
+            xv[i] = ((c == i ? 1.0 : 0.0) - s) * sm.rdiag[c0 + i];                      // 0 above the diagonal
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sm.x[c0 + i][c0 + c] = xv[i];
+        }
+    };
+
+    // T[rb, cb] -= L[rb, kb] L[cb, kb]^T (16 x 16 blocks); column block 1's three blocks go to waves 1, 2, 3, the
+    // others alternate between waves 1 and 2 (wave 3 also inverts the diagonal blocks)
+    auto block_owner = [](int rb, int cb) { return cb == 1 ? rb : (rb == 3 && cb == 2 ? 2 : 1); };
+    auto block_update = [&](int rb, int cb, int kb) {
+        double *c = &sm.t[16 * rb][16 * cb];
+        blk_store_d(c, lane, blk_mma_abt(&sm.t[16 * rb][16 * kb], &sm.t[16 * cb][16 * kb], blk_load_d(c, lane), -1.0, lane));
+    };
 
     int first_bad = PANEL;  // meaningful in wave 0
 #pragma unroll
@@ -139,38 +177,36 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
 #pragma unroll
                 for (int c = 0; c < 16; ++c) sm.t[row][c0 + c] = (c0 + c <= row) ? a[c] : 0.0;
             }
-        }
-        __syncthreads();
-        // ---- blocks right of the strip (rb >= cb > kb), round-robin over the waves
-        {
-            int q = 0;
+        } else if (wave == 3) {
+            if (kb > 0) diag_inverse(kb - 1);
+        } else if (kb > 0) {
+            // deferred updates of the strip before: the blocks that strip's successor did not need (cb > kb), done while
+            // wave 0 is in this strip's chain.  Every block belongs to one wave (cb odd: wave 1, even: wave 2 -- and
+            // (3, 3) to wave 1), which applies the strips' updates to it in order.
 #pragma unroll
             for (int rb = kb + 1; rb < 4; ++rb)
 #pragma unroll
-                for (int cb = kb + 1; cb <= rb; ++cb, ++q)
-                    if ((q & 3) == wave) {
-                        double *c = &sm.t[16 * rb][16 * cb];
-                        blk_store_d(c, lane, blk_mma_abt(&sm.t[16 * rb][c0], &sm.t[16 * cb][c0], blk_load_d(c, lane), -1.0, lane));
-                    }
-        }
-        // ---- inverse of the diagonal block: lane c < 16 owns column c of X[kb, kb]
-        if (wave == 3) {
-            const int c = lane & 15;
-            double xv[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double s = 0.0;
-#pragma unroll
-                for (int u = 0; u < i; ++u) s = __builtin_fma(sm.t[c0 + i][c0 + u], xv[u], s);  // broadcast reads
-                xv[i] = ((c == i ? 1.0 : 0.0) - s) * sm.rdiag[c0 + i];                      // 0 above the diagonal
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sm.x[c0 + i][c0 + c] = xv[i];
-            }
+                for (int cb = kb + 1; cb <= rb; ++cb)
+                    if (block_owner(rb, cb) == wave) block_update(rb, cb, kb - 1);
         }
         __syncthreads();
+        if (kb == 0 && blockIdx.x > 0) {  // the tile of A21 has landed by now: registers -> LDS, row-major like t and x
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 8; e += 2)
+                    *reinterpret_cast<double2_t *>(&sm.a21[t >> 2][32 * h + (t & 3) * 8 + e]) = (double2_t){a21[h][e], a21[h][e + 1]};
+        }
+        // ---- the blocks the NEXT strip reads, (rb, kb + 1): one per wave 1 .. 3, then wave 0 goes on
+        if (kb < 3) {
+#pragma unroll
+            for (int rb = kb + 1; rb < 4; ++rb)
+                if (block_owner(rb, kb + 1) == wave) block_update(rb, kb + 1, kb);
+            __syncthreads();
+        }
     }
+    if (wave == 3) diag_inverse(3);
+    __syncthreads();
     if (first_bad != PANEL && blockIdx.x == 0 && t == 0 && info[0] == 0) info[0] = k0 + first_bad + 1;
 
     // ---- off-diagonal blocks of X = inv(L11), by distance d from the diagonal
@@ -197,20 +233,19 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
         }
         return;
     }
-    // ---- L21 = A21 * X11^T for this block's 64 rows
+    // ---- L21 = A21 * X11^T for this block's 64 rows, straight from the two LDS images: wave w owns the row block w,
+    //      and X11 is lower triangular, so column block cb takes the k blocks 0 .. cb only (10 block products per wave
+    //      instead of 16).  (The last barrier above made X complete; A21 was staged after the first strip.)
     const int r0 = k0 + PANEL * blockIdx.x;
-    Acc64 acc;
-    acc.zero();
-    const double *pa = A + (size_t)(r0 + (t >> 2)) * ld + k0 + (t & 3) * 8;
-    tile64_mac<false>(
-        acc, sm.mm, 0, PANEL, [&](int kb, double(&v)[8]) { load8d<true>(pa + kb, v); },
-        [&](int kb, double(&v)[8]) {  // B[k][c] = X11[c][k], straight from LDS
-            const double *px = &sm.x[t >> 2][kb + (t & 3) * 8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = px[e];
-        });
-    __syncthreads();
-    tile64_foreach(acc, [&](int r, int c, double v) { A[(size_t)(r0 + r) * ld + k0 + c] = v; });
+    for (int cb = 0; cb < 4; ++cb) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k <= cb; ++k) acc = blk_mma_abt(&sm.a21[16 * wave][16 * k], &sm.x[16 * cb][16 * k], acc, 1.0, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            A[(size_t)(r0 + 16 * wave + (lane >> 4) + 4 * r) * ld + k0 + 16 * cb + (lane & 15)] = acc[r];
+    }
 }
 
 // C[bi][bj] -= L[bi][ka:kb] * L[bj][ka:kb]^T for tiles bi in [ti0, ti1), bj in [tj0, tj1), bj <= bi.

@@ -236,6 +236,23 @@ class HipBackend:
         small = n <= self.local_batch_cols or (n <= 2 * self.local_batch_cols and R <= 1024)
         return self.local_batch > 1 and small and self.engine.order_mode_code(self.act_order) in (0, 1)
 
+    def wants_stacked_loop(self, layer):
+        """Wide layers with few rows (OPT-350M / BLOOM-560M's 1024 x 4096): the n^3 factorisation fills the chip, the loop
+        does not -- its window kernel runs one workgroup per 16 rows, 64 of them for 1024 rows.  Such layers are
+        factored one by one on the factor streams and LOOPED in stacks of 4096 rows (run_round_stacked)."""
+        R, n = layer["W"].shape
+        return (self.local_batch > 1 and not self.wants_local_batch(layer) and R <= 2048
+                and self.engine.order_mode_code(self.act_order) in (0, 1))
+
+    def run_round_stacked(self, round_layers, factors):
+        """All rows of a round's layers from their own factors (order, U, info[, symmetry flag]) made elsewhere on this
+        GPU: stacked, then ONE loop / error over all of them."""
+        order = torch.stack([f[0] for f in factors])
+        U = torch.stack([f[1] for f in factors])
+        info = torch.cat([f[2] for f in factors])
+        known = torch.cat([f[3] for f in factors]) if all(len(f) > 3 for f in factors) else None
+        return self._run_stacked(round_layers, 0, round_layers[0]["W"].shape[0], order, U, info, known)
+
     def run_round_local(self, round_layers):
         """All rows of a round's layers on this rank: batched factorisation (engine.factorize_batch), then the
         stacked loop / local search / error of run_round."""
@@ -308,36 +325,77 @@ def _all_gather_words(payload, size):
     return outs, dist.all_gather(outs, payload, async_op=True)
 
 
-def _quantize_stream_local(layers, small, backend, join):
-    """One rank, a stream with small layers in it (quantize_stream): the small ones in batched rounds by shape, one round
-    after the other on alternating streams (a round is a chain of short launches: two or three in flight fill the gaps);
-    the rest through the usual route."""
+def _quantize_stream_local(layers, small, short, backend, join):
+    """One rank, a stream with small or short layers in it (quantize_stream).  `small` layers go in batched rounds by
+    shape -- factored AND looped together -- one round after the other on alternating streams (a round is a chain of short
+    launches: two or three in flight fill the gaps); `short` ones (wide, few rows) are factored one by one on the factor
+    streams and looped in stacks; the rest through the usual route."""
     n_layers = len(layers)
     out = [None] * n_layers
     fstreams, _, lstreams = backend.streams()
-    pool = (fstreams + lstreams) if fstreams is not None else [None]
-    here = torch.cuda.current_stream() if pool[0] is not None else None
-    rounds, _ = plan_rounds([layers[l] for l in small], backend.local_batch)
-    for st in pool:
-        if st is not None:
-            st.wait_stream(here)
-    for i, members in enumerate(rounds):
-        st = pool[i % len(pool)]
-        idxs = [small[m] for m in members]
-        with (torch.cuda.stream(st) if st is not None else _NullCtx()):
-            if len(idxs) == 1:
-                lay = layers[idxs[0]]
-                fac = backend.factorize(lay)
-                shards = [dict(backend.run_rows(lay, 0, lay["W"].shape[0], fac), info=fac[2])]
-            else:
-                shards = backend.run_round_local([layers[l] for l in idxs])
+    side = fstreams is not None
+    pool = (fstreams + lstreams) if side else [None]
+    here = torch.cuda.current_stream() if side else None
+
+    def on(st):
+        return torch.cuda.stream(st) if st is not None else _NullCtx()
+
+    def keep(shards, idxs):
         for l, shard in zip(idxs, shards):
             out[l] = shard
             if here is not None:
                 for t in shard.values():
                     if isinstance(t, torch.Tensor):
                         t.record_stream(here)
-    rest = [l for l in range(n_layers) if l not in set(small)]
+
+    for st in pool:
+        if st is not None:
+            st.wait_stream(here)
+    if small:
+        rounds, _ = plan_rounds([layers[l] for l in small], backend.local_batch)
+        for i, members in enumerate(rounds):
+            st = pool[i % len(pool)]
+            idxs = [small[m] for m in members]
+            with on(st):
+                if len(idxs) == 1:
+                    lay = layers[idxs[0]]
+                    fac = backend.factorize(lay)
+                    shards = [dict(backend.run_rows(lay, 0, lay["W"].shape[0], fac), info=fac[2])]
+                else:
+                    shards = backend.run_round_local([layers[l] for l in idxs])
+            keep(shards, idxs)
+    if short:
+        # factorisations rotate over the factor streams, every round's stacked loop goes to the loop stream behind them
+        ls = lstreams[0] if side else None
+        rotation = getattr(backend, "_factor_rotation", 0) if side else 0
+        for members in _short_rounds(layers, short, backend):
+            facs, events = [], []
+            for l in members:
+                fs = fstreams[rotation % len(fstreams)] if side else None
+                rotation += 1
+                with on(fs):
+                    facs.append(backend.factorize(layers[l]))
+                    if side:
+                        ev = torch.cuda.Event()
+                        ev.record(fs)
+                        events.append(ev)
+            with on(ls):
+                for ev in events:
+                    ls.wait_event(ev)
+                if len(members) == 1:
+                    lay = layers[members[0]]
+                    shards = [dict(backend.run_rows(lay, 0, lay["W"].shape[0], facs[0]), info=facs[0][2])]
+                else:
+                    shards = backend.run_round_stacked([layers[l] for l in members], facs)
+                if side:
+                    for f in facs:
+                        for t in f:
+                            t.record_stream(ls)
+            keep(shards, members)
+        if side:
+            backend._factor_rotation = rotation % len(fstreams)
+    taken = set(small) | set(short)
+    rest = [l for l in range(n_layers) if l not in taken]
     if rest:
         for l, shard in zip(rest, quantize_stream([layers[l] for l in rest], backend, join=join, _local=False)):
             out[l] = shard
@@ -345,6 +403,18 @@ def _quantize_stream_local(layers, small, backend, join):
         for st in pool:
             here.wait_stream(st)
     return out
+
+
+def _short_rounds(layers, short, backend):
+    """Rounds of same-shaped `short` layers whose stacked rows come to about a full layer's worth (4096)."""
+    by_shape = {}
+    for l in short:
+        by_shape.setdefault((tuple(layers[l]["W"].shape), layers[l].get("scale") is not None), []).append(l)
+    rounds = []
+    for (shape, _), members in by_shape.items():
+        per = max(2, min(backend.local_batch, 4096 // max(shape[0], 1)))
+        rounds.extend(members[i:i + per] for i in range(0, len(members), per))
+    return rounds
 
 
 def quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
@@ -377,8 +447,10 @@ def quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
     if size == 1 and not always_exchange and _local and hasattr(backend, "run_round_local"):
         # one rank: small layers go in rounds of one shape, factored and looped in launches that cover the round
         small = [l for l in range(n_layers) if backend.wants_local_batch(layers[l])]
-        if len(small) > 1:
-            return _quantize_stream_local(layers, small, backend, join)
+        short = [l for l in range(n_layers) if backend.wants_stacked_loop(layers[l])]
+        small, short = (small if len(small) > 1 else []), (short if len(short) > 1 else [])
+        if small or short:
+            return _quantize_stream_local(layers, small, short, backend, join)
     fstreams, cstream, lstreams = backend.streams() if hasattr(backend, "streams") else (None, None, None)
     side = fstreams is not None
     here = torch.cuda.current_stream() if side else None

@@ -99,18 +99,22 @@ def test_small_layers_in_batched_rounds_on_one_rank(moves):
 
     dev = torch.device("cuda", 0)
     cb = codebook.UniformCodebook(8, -1, 1)
-    shapes = [(256, 192), (100, 320), (128, 1100), (256, 192), (100, 320), (256, 192), (64, 2048), (100, 320)]
+    shapes = [(256, 192), (100, 320), (128, 1100), (256, 192), (100, 320), (256, 192), (64, 2048), (100, 320), (48, 172), (48, 172),
+              (1100, 1600), (1100, 1600), (1100, 1600)]  # the last three: wide with few rows -> factored singly, looped as a stack
     layers = []
     for i, (R, n) in enumerate(shapes):
         L = synth.make_layer(R, n, 3100 + i)
         layers.append({k: torch.from_numpy(L[k]).to(dev) for k in ("W", "H", "scale")})
     be = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True)
-    calls = {"local": 0}
-    run_local = be.run_round_local
+    calls = {"local": 0, "stacked": 0}
+    run_local, run_stacked = be.run_round_local, be.run_round_stacked
     be.run_round_local = lambda members: (calls.__setitem__("local", calls["local"] + 1), run_local(members))[1]
+    be.run_round_stacked = lambda members, facs: (calls.__setitem__("stacked", calls["stacked"] + 1), run_stacked(members, facs))[1]
     shards = sdist.quantize_stream(layers, be)
     torch.cuda.synchronize()
-    assert calls["local"] == 2  # (256, 192) x 3 and (100, 320) x 3; 1100 and 2048 columns alone
+    assert calls["local"] == 3  # (256, 192) x 3, (100, 320) x 3 and (48, 172) x 2 (172 columns: padded to 192 inside the
+    #                              factorisation, 48 rows: padded to a tile); 1100 and 2048 columns alone
+    assert calls["stacked"] == 1
     for lay, sh in zip(layers, shards):
         res = engine.quantize_layer(lay["W"], lay["H"], cb, lay["scale"], nb_ls_moves=moves)
         err = engine.row_errors(lay["W"], res.Q, lay["H"])

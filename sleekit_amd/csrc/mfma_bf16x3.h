@@ -158,15 +158,23 @@ __device__ __forceinline__ void tile128_mac_dma(Acc128 &acc, TileBf16DmaSmem &sm
     const unsigned short *gb = b_slabs + (size_t)(k_begin >> 5) * 4096 + wave * 1024 + lane * 8;
     const int sw = ((lane & 31) >> 2) & 3;
     const int r_off0 = (lane & 31) * 64 + (((lane >> 5) ^ sw) * 16), r_off1 = (lane & 31) * 64 + ((((lane >> 5) + 2) ^ sw) * 16);
-    for (int k0 = k_begin; k0 < k_end; k0 += KB16, ga += 4096, gb += 4096) {
-        __syncthreads();  // the previous round's reads are done
+    // One LDS buffer, but the copy of round r + 1 is in flight while the MFMAs of round r run: the operands of a round are
+    // read into registers first (barrier: every wave has them), THEN the next round's copy is issued, then the MFMAs.
+    // (Measured against issuing the copy at the top of the round and waiting for it there: 0.441 against 0.445 ms for the
+    // layer error of a 4096 x 4096 layer -- the three workgroups of a CU already overlap one another's copies; what bounds
+    // the kernel is the rate at which a CU pulls operands out of L2, 48 KB per 6.3 Mflop round.)
+    auto copy_round = [&](const unsigned short *pa, const unsigned short *pb) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                __builtin_amdgcn_global_load_lds(ga + p * a_plane + i * 512, sm.a[p] + wave * 2048 + i * 1024, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(gb + p * b_plane + i * 512, sm.b[p] + wave * 2048 + i * 1024, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(pa + p * a_plane + i * 512, sm.a[p] + wave * 2048 + i * 1024, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(pb + p * b_plane + i * 512, sm.b[p] + wave * 2048 + i * 1024, 16, 0, 0);
             }
+    };
+    __syncthreads();  // whatever used this LDS before is done
+    copy_round(ga, gb);
+    for (int k0 = k_begin; k0 < k_end; k0 += KB16) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's copies have landed before it passes the barrier
         __syncthreads();
         bf16x8_t a[2][2][3], b[2][2][3];  // [s][i][plane]
@@ -179,6 +187,13 @@ __device__ __forceinline__ void tile128_mac_dma(Acc128 &acc, TileBf16DmaSmem &sm
                     a[s][i][p] = *reinterpret_cast<const bf16x8_t *>(sm.a[p] + (wr * 64 + i * 32) * 64 + (s ? r_off1 : r_off0));
                     b[s][i][p] = *reinterpret_cast<const bf16x8_t *>(sm.b[p] + (wc * 64 + i * 32) * 64 + (s ? r_off1 : r_off0));
                 }
+        ga += 4096, gb += 4096;
+        if (k0 + KB16 < k_end) {
+            // (the reads above must have completed in EVERY wave before the copy overwrites the buffer)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            copy_round(ga, gb);
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll

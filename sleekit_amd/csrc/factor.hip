@@ -260,11 +260,15 @@ __global__ __launch_bounds__(256) void k_syrk_tiles(double *__restrict__ A, int 
     const int t = threadIdx.x;
     const double *pa = A + ((size_t)bi * TILE + (t >> 2)) * ld + (t & 3) * 8;
     const double *pb = A + ((size_t)bj * TILE + (t >> 2)) * ld + (t & 3) * 8;
+    // the tile of C is fetched NOW, not when the products are done: its trip to memory then hides behind them instead of
+    // sitting at the tail of this K = 64 update (at most ~240 workgroups: registers are free)
+    double *pc = A + (size_t)bi * TILE * ld + (size_t)bj * TILE;
+    Acc64 old;
+    tile64_map(old, [&](int r, int c) { return pc[(size_t)r * ld + c]; });
     tile64_mac<false>(
         acc, sm, ka, kb, [&](int k0, double(&v)[8]) { load8d<true>(pa + k0, v); },
         [&](int k0, double(&v)[8]) { load8d<true>(pb + k0, v); });
-    double *pc = A + (size_t)bi * TILE * ld + (size_t)bj * TILE;
-    tile64_foreach(acc, [&](int r, int c, double v) { pc[(size_t)r * ld + c] -= v; });
+    tile64_foreach2(old, acc, [&](int r, int c, double o, double v) { pc[(size_t)r * ld + c] = o - v; });
 }
 
 // The same update over the whole lower triangle of tiles [t0, nt) x [t0, nt), one-dimensional grid in
@@ -290,6 +294,8 @@ __global__ __launch_bounds__(256) void k_syrk_triangle(double *__restrict__ A, i
     tile64_mac<false>(
         acc, sm, ka, kb, [&](int k0, double(&v)[8]) { load8d<true>(pa + k0, v); },
         [&](int k0, double(&v)[8]) { load8d<true>(pb + k0, v); });
+    // (fetching the tile of C before the products, as the inner update does, costs 48 registers: 3 waves per SIMD
+    // instead of 4, which this chip-wide kernel needs more than the shorter tail)
     double *pc = A + (size_t)bi * TILE * ld + (size_t)bj * TILE;
     tile64_foreach(acc, [&](int r, int c, double v) { pc[(size_t)r * ld + c] -= v; });
 }

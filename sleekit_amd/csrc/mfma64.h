@@ -224,4 +224,30 @@ __device__ __forceinline__ void tile64_foreach(const Acc64 &acc, F f) {
                 f(wr * 32 + i * 16 + (lane >> 4) + 4 * r, wc * 32 + j * 16 + (lane & 15), acc.c[i][j][r]);
 }
 
+// Fill an accumulator-shaped register tile: value(row, col), tile-local coordinates (same element -> thread map as above).
+template <class F>
+__device__ __forceinline__ void tile64_map(Acc64 &acc, F value) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.c[i][j][r] = value(wr * 32 + i * 16 + (lane >> 4) + 4 * r, wc * 32 + j * 16 + (lane & 15));
+}
+// Visit two tiles element by element: f(row, col, a, b).
+template <class F>
+__device__ __forceinline__ void tile64_foreach2(const Acc64 &x, const Acc64 &y, F f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                f(wr * 32 + i * 16 + (lane >> 4) + 4 * r, wc * 32 + j * 16 + (lane & 15), x.c[i][j][r], y.c[i][j][r]);
+}
+
 }  // namespace slk

@@ -363,16 +363,22 @@ def main():
     # ---- one isolated layer, start to finish ("report the single-layer number separately")
     latency = None
     if extras:
+        # through the single-layer API (sleekit_amd.engine.quantize_layer + row_errors: what scaling.quantize_with_scaling
+        # and obq.quantization_error run on device tensors), where the factorisation looks ahead on a helper stream
+        from sleekit_amd import engine
+
         lat = []
         for i in range(6):
+            lay = strip_mean(layers[i % L]) if strip else layers[i % L]
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            one = [layers[i % L]]
-            sdist.quantize_stream([strip_mean(one[0])] if strip else one, backend, join=True)
+            res = engine.quantize_layer(lay["W"], lay["H"], cb, lay["scale"], "diag", 0.01, moves)
+            engine.row_errors(lay["W"], res.Q, lay["H"])
             torch.cuda.synchronize()
             lat.append(1e3 * (time.perf_counter() - t1))
+        dev.raise_pending()
         latency = {"ms": round(float(np.median(lat[1:])), 3), "shape": list(shapes[0]) if len(set(shapes)) == 1 else [list(shapes[i % L]) for i in range(1, 6)],
-                   "note": "median of 5 after one warm-up: a single layer alone on the GPU, host call to synchronize"}
+                   "note": "median of 5 after one warm-up: a single layer alone on the GPU through engine.quantize_layer + row_errors, host call to synchronize"}
 
     # ---- the same workload on Hessians that are NOT bit-symmetric (made by a library GEMM, like the experiments' dumps
     #      of torch `inp @ inp.t()`): the layer error cannot halve its work then

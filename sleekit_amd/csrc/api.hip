@@ -179,7 +179,7 @@ namespace {
 const char *const kOptNames[OPT_COUNT] = {
     "NO_FAST_LEAF", "NO_DEFER", "NO_WINDOW2", "WIN_DBG", "NO_REGULAR_SEARCH", "NO_FAST_SEARCH_DIV",
     "NO_ERROR_SPLITK", "ERROR_CB", "NO_SYM_ERROR", "NO_BF16_ERROR", "NO_BF16_DMA", "NO_BF16_HESSIAN",
-    "ERROR_F32_BELOW", "NO_BF16_ASYM",
+    "ERROR_F32_BELOW", "NO_BF16_ASYM", "LOOKAHEAD",
 };
 std::atomic<int> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;
@@ -209,6 +209,32 @@ std::map<std::pair<const void *, int>, size_t> g_lds_set;
 int opt(Opt o) {
     std::call_once(g_opts_once, opts_from_env);
     return g_opts[o].load(std::memory_order_relaxed);
+}
+
+namespace {
+std::mutex g_helper_mu;
+std::map<std::pair<int, hipStream_t>, Helper> g_helpers;
+}  // namespace
+
+hipError_t helper_for(hipStream_t main, Helper *out) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_helper_mu);
+    auto it = g_helpers.find({device, main});
+    if (it == g_helpers.end()) {
+        Helper h;
+        e = hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        h.events = new hipEvent_t[HELPER_EVENTS];
+        for (int i = 0; i < HELPER_EVENTS; ++i) {
+            e = hipEventCreateWithFlags(&h.events[i], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        it = g_helpers.emplace(std::make_pair(device, main), h).first;
+    }
+    *out = it->second;
+    return hipSuccess;
 }
 
 hipError_t lds_opt_in(const void *kernel, size_t bytes) {

@@ -80,9 +80,20 @@ enum Opt {
     OPT_NO_BF16_HESSIAN,       // Hessian accumulation: float32 MFMA kernel
     OPT_ERROR_F32_BELOW,       // layer error of a batch: float32 kernel when a layer has fewer rows than this (0: 1024, < 0: never)
     OPT_NO_BF16_ASYM,          // layer error: an H that is not symmetric goes to the float32 kernel
+    OPT_LOOKAHEAD,             // factorisation: the bulk of an outer syrk on a helper stream, beside the next block's panels
     OPT_COUNT
 };
 int opt(Opt o);
+
+// A helper stream beside the caller's (one per (device, caller stream), created at first use, with a pool of events):
+// the factorisation forks the bulk of an outer syrk onto it and joins again before it returns, so the caller still sees
+// one stream.  Fork and join are event record / wait pairs, which a hipGraph capture of the caller's stream follows.
+struct Helper {
+    hipStream_t stream;
+    hipEvent_t *events;  // HELPER_EVENTS of them
+};
+constexpr int HELPER_EVENTS = 512;
+hipError_t helper_for(hipStream_t main, Helper *out);
 
 // Opt a kernel in to `bytes` of dynamic LDS (above the 64 KB default) on the CURRENT device; remembered per
 // (kernel, device), safe to call from several threads.  Returns a hipError_t.

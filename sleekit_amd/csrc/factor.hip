@@ -22,6 +22,7 @@ namespace slk {
 
 constexpr int PANEL = 64;
 constexpr int OUTER = 256;
+constexpr int LOOKAHEAD_MIN_TILES = 24;  // trailing tile rows from which an outer syrk is split (below it lasts < 25 us whole)
 
 constexpr int TP = 66;  // pitch of the 64 x 64 LDS tiles: MFMA operand reads walk banks 4 row + 2 k
 
@@ -379,6 +380,15 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
     SLK_LDS_OPT_IN(k_chol_panel, sizeof(PanelSmem));
     SLK_RUN_W("clear_info", 0, 4, 1, s, k_clear_info<<<B, 1, 0, s>>>(info));
 
+    // Look-ahead over the outer blocks (below): a helper stream and events.  For ONE factorisation at a time it takes
+    // 0.6 ms off a 4096-column layer (6.2 -> 5.6 ms end to end); with several factorisations in flight on streams of
+    // their own (sleekit_amd.dist) the extra streams push the process past its 8 hardware queues, streams start sharing
+    // queues and stop overlapping (4830 -> 3560 Mweights/s on one rank, 4.7 -> 7.3 ms per step of a rank of 8).  So it is
+    // a switch, off by default, which the single-layer API turns on (sleekit_amd/engine.py: quantize_layer).
+    Helper helper{};
+    const bool lookahead = opt(OPT_LOOKAHEAD) && nt >= LOOKAHEAD_MIN_TILES + OUTER / TILE && nt / (OUTER / TILE) < HELPER_EVENTS / 2;
+    if (lookahead) SLK_HIP(helper_for(s, &helper));
+    int block = 0, forked = -1;  // forked: the last block whose rest went to the helper and has not been joined
     for (int K0 = 0; K0 < ld; K0 += OUTER) {
         const int K1 = K0 + OUTER < ld ? K0 + OUTER : ld;
         for (int k0 = K0; k0 < K1; k0 += PANEL) {
@@ -400,10 +410,36 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
         if (nt > t0) {
             const int m = nt - t0, total = m * (m + 1) / 2;
             const double tiles = total;
-            SLK_RUN_W("chol_syrk_outer", Bd * tiles * 2.0 * 64 * 64 * (K1 - K0), Bd * (8.0 * (ld - K1) * (K1 - K0) + tiles * 16.0 * 64 * 64),
-                      tiles * batch, s, k_syrk_triangle<<<dim3(8 * ((total + 7) / 8), 1, B), 256, 0, s>>>(A, ld, t0, m, K0, K1));
+            const int ahead = OUTER / TILE;  // tile columns of the next outer block
+            if (lookahead && m >= LOOKAHEAD_MIN_TILES) {
+                // LOOK-AHEAD.  Only the next outer block's columns are needed before its panels can start: those
+                // (4 m - 6 tiles) are updated here, on the caller's stream; the rest of the triangle goes to the helper
+                // stream and runs beside the next block's panels (<= 64 workgroups each), which it used to hold up.
+                // Same tiles, same K ranges, a fixed order per tile (events below), so the results do not depend on timing.
+                if (block > 0) SLK_HIP(hipStreamWaitEvent(s, helper.events[2 * (block - 1) + 1], 0));  // rest of block - 1 is in
+                SLK_HIP(hipEventRecord(helper.events[2 * block], s));                                // panels of this block are done
+                const double ta = (double)ahead * m - 6;
+                SLK_RUN_W("chol_syrk_ahead", Bd * ta * 2.0 * 64 * 64 * (K1 - K0), Bd * (8.0 * (ld - K1) * (K1 - K0) + ta * 16.0 * 64 * 64),
+                          ta * batch, s, k_syrk_tiles<<<dim3(ahead, m, B), 256, 0, s>>>(A, ld, t0, t0, K0, K1));
+                SLK_HIP(hipStreamWaitEvent(helper.stream, helper.events[2 * block], 0));
+                const int m2 = m - ahead, total2 = m2 * (m2 + 1) / 2;
+                SLK_RUN_W("chol_syrk_outer", Bd * total2 * 2.0 * 64 * 64 * (K1 - K0), Bd * (8.0 * (ld - K1) * (K1 - K0) + total2 * 16.0 * 64 * 64),
+                          (double)total2 * batch, helper.stream,
+                          k_syrk_triangle<<<dim3(8 * ((total2 + 7) / 8), 1, B), 256, 0, helper.stream>>>(A, ld, t0 + ahead, m2, K0, K1));
+                SLK_HIP(hipEventRecord(helper.events[2 * block + 1], helper.stream));
+                forked = block;
+            } else {
+                if (forked >= 0) {  // the helper's last piece touches these tiles too: join first
+                    SLK_HIP(hipStreamWaitEvent(s, helper.events[2 * forked + 1], 0));
+                    forked = -1;
+                }
+                SLK_RUN_W("chol_syrk_outer", Bd * tiles * 2.0 * 64 * 64 * (K1 - K0), Bd * (8.0 * (ld - K1) * (K1 - K0) + tiles * 16.0 * 64 * 64),
+                          tiles * batch, s, k_syrk_triangle<<<dim3(8 * ((total + 7) / 8), 1, B), 256, 0, s>>>(A, ld, t0, m, K0, K1));
+            }
         }
+        ++block;
     }
+    if (forked >= 0) SLK_HIP(hipStreamWaitEvent(s, helper.events[2 * forked + 1], 0));
     for (int lvl = 1; lvl < nt; lvl *= 2) {
         const int nodes = (nt + 2 * lvl - 1) / (2 * lvl);
         dim3 grid(nodes * lvl * lvl, 1, B);

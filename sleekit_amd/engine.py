@@ -78,8 +78,14 @@ class LayerResult:
         self.Q = self.idx = self.order = self.U = self.info = self.E = self.ls_trace = None
 
 
-def factorize(H, n, damp, mode, miss=None, keep=None):
-    """Damping + order + float64 factor for a float32 device Hessian. Returns (order, U, info)."""
+def factorize(H, n, damp, mode, miss=None, keep=None, lookahead=False):
+    """Damping + order + float64 factor for a float32 device Hessian. Returns (order, U, info).
+    lookahead: one layer at a time (latency matters, nothing else is in flight): the factorisation forks the bulk of
+    its outer updates onto a helper stream (slk_set_option "lookahead"; off for the multi-stream pipelines of
+    sleekit_amd.dist, where the extra streams cost more than they save)."""
+    if lookahead:
+        with _lib.option("lookahead", 1):
+            return factorize(H, n, damp, mode, miss, keep)
     ws, ws_bytes = dev.workspace(0, n)
     s = dev.stream_handle()
     ld = _lib.lib.slk_factor_ld(n)
@@ -251,7 +257,7 @@ def row_errors(W, Q, H, want_G=False):
 
 def quantize_layer(
     W, H, quantizer, scale=None, act_order="diag", damp=0.01, nb_ls_moves=0, min_block_size=32, num_blocks=8,
-    factor=None, unscale=True, want_idx=True, want_ls_trace=False,
+    factor=None, unscale=True, want_idx=True, want_ls_trace=False, lookahead=True,
 ):
     """One layer through the whole path, on device tensors.
 
@@ -260,6 +266,7 @@ def quantize_layer(
     LayerResult whose Q is de-scaled when `scale` is given and `unscale` is true
     (sleekit/scaling.py:58-81), else the codebook values in the scaled domain
     (sleekit/obq.py:169-217).  want_ls_trace: res.ls_trace = the local search's moves (slk_local_search).
+    lookahead: see factorize (one layer at a time: on).
     """
     assert W.ndim == 2
     assert H.ndim == 2
@@ -279,7 +286,7 @@ def quantize_layer(
             miss = order_keys(H, n, damp, act_order)
         else:
             miss = column_miss(Ws, cb_abi, mode == _lib.ORDER_SQERR) if mode >= _lib.ORDER_ERR else None
-        factor = factorize(H, n, damp, mode, miss)
+        factor = factorize(H, n, damp, mode, miss, lookahead=lookahead)
         dev.note_info(factor[2], "compute_hessian_chol")
     res.order, res.U, res.info = factor
 

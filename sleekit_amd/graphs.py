@@ -39,7 +39,8 @@ class GraphedLayer:
 
     def _body(self):
         quantizer, act_order, damp = self.args
-        res = engine.quantize_layer(self.W, self.H, quantizer, self.scale, act_order, damp)
+        # (no look-ahead inside a capture: graphs of several layers replay side by side on streams of their own)
+        res = engine.quantize_layer(self.W, self.H, quantizer, self.scale, act_order, damp, lookahead=False)
         self.Q, self.idx, self.info = res.Q, res.idx, res.info
         self.row_err = engine.row_errors(self.W, res.Q, self.H) if self.with_error else None
 

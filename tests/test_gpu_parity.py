@@ -227,6 +227,18 @@ def test_order_and_factor(amd, R, n, seed):
     assert np.abs(got_U.T @ got_U @ P - np.eye(n)).max() < 1e-8
 
 
+def test_factor_lookahead_changes_nothing(amd):
+    """The single-layer API lets the factorisation look ahead (the bulk of every outer update on a helper stream, beside the
+    next block's panels): every tile still receives the same updates in the same order, so U is the same bit for bit."""
+    n = 2560  # 40 tile rows: outer blocks with 36, 32, 28 and 24 trailing rows fork
+    L = synth.make_layer_device(8, n, 4100, torch.device("cuda"))
+    o0, U0, i0 = amd.engine.factorize(L["H"], n, 0.01, amd.lib.ORDER_DIAG)
+    o1, U1, i1 = amd.engine.factorize(L["H"], n, 0.01, amd.lib.ORDER_DIAG, lookahead=True)
+    torch.cuda.synchronize()
+    assert amd.lib.lib.slk_get_option(b"lookahead") == 0  # (restored)
+    assert torch.equal(o0, o1) and torch.equal(U0, U1) and int(i0.item()) == int(i1.item()) == 0
+
+
 def test_factor_of_plain_matrix_and_not_pd(amd):
     rng = np.random.default_rng(11)
     A = rng.standard_normal((200, 150))

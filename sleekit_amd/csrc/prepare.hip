@@ -19,6 +19,36 @@ __global__ __launch_bounds__(256) void k_diag_mean(const PtrTable hs, int n, int
     if (threadIdx.x == 0) out[0] = total / (float)n;
 }
 
+// The head of slk_hessian_prepare in ONE launch (one workgroup per layer; n <= 16384): mean(diag H) in NumPy's order
+// (the workgroup sum of the local search, npsum.h: HeapSum -- its tree needs no serial construction), the damping term,
+// the sort keys and the zeroed rank counters -- three dependent launches of a few microseconds each before (the mean
+// alone took 29 us at n = 4096, most of it one thread building the summation tree).
+__global__ __launch_bounds__(256) void k_diag_prepare(const PtrTable hs, int n, float damp, const float *__restrict__ miss,
+                                                      float *__restrict__ scal, double *__restrict__ keys, int *__restrict__ rank,
+                                                      int want_rank) {
+    __shared__ HeapSum plan;
+    extern __shared__ float diag_terms[];  // heap_sum_floats(n)
+    const float *__restrict__ H = hs.p[blockIdx.z];
+    scal += 64 * blockIdx.z;
+    if (keys) keys += (size_t)n * blockIdx.z;
+    if (rank) rank += (size_t)n * blockIdx.z;
+    heap_sum_plan(plan, n);
+    for (int j = threadIdx.x; j < n; j += 256) diag_terms[heap_sum_pos(j)] = H[(size_t)j * n + j];
+    const float mean = heap_sum(plan, diag_terms, n) / (float)n;
+    const float add = damp * mean;  // float32 product (obq.py:198 under NEP 50)
+    if (threadIdx.x == 0) {
+        scal[0] = mean;
+        if (keys) scal[1] = add;
+    }
+    if (keys == nullptr) return;  // (slk_diag_mean: the mean alone)
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double k = -((double)diag_terms[heap_sum_pos(i)] + (double)add);
+        if (miss) k = k * (double)miss[i];
+        keys[i] = k;
+        if (want_rank) rank[i] = 0;
+    }
+}
+
 // ------------------------------------------------------------------ order keys
 // key[i] = -(double(H_ii) + damp_add) [* double(miss_i)]     (obq.py:64, 69, 81)
 // scal[0] = mean(diag); scal[1] <- damp_add = float32(damp) * mean   (float32 product)
@@ -424,6 +454,12 @@ int slk_pivot_keys(const float *H, int n, float damp, double *keys, void *worksp
 int slk_diag_mean(const float *H, int n, float *out, void *, size_t, slk_stream_t stream) {
     SLK_REQUIRE(H && out && n > 0, "bad arguments");
     hipStream_t s = as_stream(stream);
+    if (n <= 16384) {  // the kernel slk_hessian_prepare uses
+        const size_t lds = (size_t)(n + 8 * (n / 128) + 8) * sizeof(float);
+        SLK_LDS_OPT_IN(k_diag_prepare, lds);
+        SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_prepare<<<1, 256, lds, s>>>(one_h(H), n, 0.0f, nullptr, out, nullptr, nullptr, 0));
+        return SLK_OK;
+    }
     SLK_RUN_W("diag_mean", 0, 4.0 * n, 1, s, k_diag_mean<<<1, 256, 0, s>>>(one_h(H), n, n, out));
     return SLK_OK;
 }
@@ -443,15 +479,23 @@ static int hessian_prepare_impl(const PtrTable &hs, int batch, int n, float damp
     const unsigned B = (unsigned)batch;
     bool aligned = true;
     for (int b = 0; b < batch; ++b) aligned = aligned && (uintptr_t)hs.p[b] % 16 == 0;
-    SLK_RUN_W("diag_mean", 0, 4.0 * n * batch, batch, s, k_diag_mean<<<dim3(1, 1, B), 256, 0, s>>>(hs, n, n, scal));
     const bool weighted = order_mode == SLK_ORDER_ERR || order_mode == SLK_ORDER_SQERR;
-    SLK_RUN("order_keys", 0, 12.0 * n * batch, s,
-            k_order_keys<<<dim3((n + 255) / 256, 1, B), 256, 0, s>>>(hs, n, damp, weighted ? miss : nullptr, scal, keys));
+    const int identity = order_mode == SLK_ORDER_NONE;
+    const bool fused = n <= 16384;
+    if (fused) {
+        const size_t lds = (size_t)(n + 8 * (n / 128) + 8) * sizeof(float);  // heap_sum_floats(n)
+        SLK_LDS_OPT_IN(k_diag_prepare, lds);
+        SLK_RUN_W("diag_prepare", 0, 16.0 * n * batch, batch, s,
+                  k_diag_prepare<<<dim3(1, 1, B), 256, lds, s>>>(hs, n, damp, weighted ? miss : nullptr, scal, keys, rank, !identity));
+    } else {
+        SLK_RUN_W("diag_mean", 0, 4.0 * n * batch, batch, s, k_diag_mean<<<dim3(1, 1, B), 256, 0, s>>>(hs, n, n, scal));
+        SLK_RUN("order_keys", 0, 12.0 * n * batch, s,
+                k_order_keys<<<dim3((n + 255) / 256, 1, B), 256, 0, s>>>(hs, n, damp, weighted ? miss : nullptr, scal, keys));
+    }
     if (order_mode == SLK_ORDER_KEYS)  // caller-supplied float64 sort keys (ascending)
         copy_async(keys, miss, sizeof(double) * (size_t)n, s);
-    const int identity = order_mode == SLK_ORDER_NONE;
     if (!identity) {
-        zero_async(rank, sizeof(int) * (size_t)n * batch, s);
+        if (!fused) zero_async(rank, sizeof(int) * (size_t)n * batch, s);
         const int slices = 16, slice = (n + slices - 1) / slices;
         SLK_RUN("rank_partial", 0, 16.0 * n * batch, s,
                 k_rank_partial<<<dim3((n + 255) / 256, slices, B), 256, 0, s>>>(keys, n, slice, rank));

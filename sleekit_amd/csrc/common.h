@@ -80,6 +80,7 @@ enum Opt {
     OPT_NO_BF16_HESSIAN,       // Hessian accumulation: float32 MFMA kernel
     OPT_ERROR_F32_BELOW,       // layer error of a batch: float32 kernel when a layer has fewer rows than this (0: 1024, < 0: never)
     OPT_NO_BF16_ASYM,          // layer error: an H that is not symmetric goes to the float32 kernel
+    OPT_NO_WAVE_SEARCH,        // local search: the workgroup-per-row kernel for every row length
     OPT_LOOKAHEAD,             // factorisation: the bulk of an outer syrk on a helper stream, beside the next block's panels
     OPT_COUNT
 };

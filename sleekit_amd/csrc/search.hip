@@ -191,6 +191,136 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same search with ONE WAVE per row, for row lengths whose NumPy summation tree is regular and small:
+// n = L leaves of m elements (m <= 128, a multiple of 8; L = 8 or 16), i.e. 8 L = 64 or 128 of NumPy's accumulator
+// chains -- one or two per lane.  Lane l, register set s holds chain c = l + 64 s: leaf c >> 3, accumulator c & 7, the
+// columns leaf * m + (c & 7) + 8 i.  A move then needs no LDS and no barrier: the chain is added up in the lane, the 8
+// accumulators of a leaf are 8 neighbouring lanes (xor-shuffles 1, 2, 4 give NumPy's ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))),
+// the 8 leaves of a register set the shuffles 8, 16, 32 (NumPy's halving), two sets one more add.  Four rows per
+// workgroup and no barrier in the move: 135 -> 95 us for 3072 x 1024 with 10 moves (taken from 2048 rows up, see the
+// dispatch below).  Same arithmetic in the same order: bit-equal to k_local_search.
+template <int M8, int S>
+__global__ __launch_bounds__(256) void k_local_search_wave(const float *__restrict__ W, float *__restrict__ Q,
+                                                           const float *__restrict__ H, const float *__restrict__ G,
+                                                           const float *__restrict__ hdiag, int R, int n, Grid g, int moves,
+                                                           uint8_t *__restrict__ idx, int *__restrict__ trace,
+                                                           float *__restrict__ gains, int gains_mode) {
+    constexpr int EPT = M8 * S;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;  // (whole waves: no barrier anywhere below)
+    const int m = 8 * M8;
+    const size_t base = (size_t)row * n;
+    const float NEG = -__builtin_huge_valf();
+    int col[EPT];
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2)
+#pragma unroll
+        for (int i = 0; i < M8; ++i) col[s2 * M8 + i] = ((lane >> 3) + 8 * s2) * m + (lane & 7) + 8 * i;
+
+    float w[EPT], q[EPT], gu[EPT], gd[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int j = col[e];
+        w[e] = W[base + j];
+        q[e] = Q[base + j];
+        if (gains_mode == 2) {
+            gu[e] = gains[2 * base + j];
+            gd[e] = gains[2 * base + n + j];
+        } else {
+            const float gj = G[base + j], hjj = hdiag[j];
+            const float du = cand_up(q[e], g) - q[e];
+            const float dd = cand_down(q[e], g) - q[e];
+            gu[e] = (-(du * du)) * hjj + (2.0f * gj) * du;
+            gd[e] = (-(dd * dd)) * hjj + (2.0f * gj) * dd;
+        }
+    }
+
+    int mv = 0;
+    for (; mv < moves; ++mv) {
+        Best bu = {NEG, 0x7fffffff, 0.0f}, bd = {NEG, 0x7fffffff, 0.0f};
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            // (a lane's columns do not come in increasing order across its register sets: ties by column, like np.argmax)
+            bu = better(bu, Best{gu[e], col[e], q[e]});
+            bd = better(bd, Best{gd[e], col[e], q[e]});
+        }
+        bu = wave_best(bu);
+        bd = wave_best(bd);
+        const bool go_up = (bu.v > bd.v) && (bu.v > 0.0f);
+        const bool go_down = !go_up && (bd.v > 0.0f);
+        if (!go_up && !go_down) break;
+        const int c = go_up ? bu.j : bd.j;
+        const float q_old = go_up ? bu.q : bd.q;
+        const float q_new = go_up ? cand_up(q_old, g) : cand_down(q_old, g);
+        if (q_new == q_old) break;  // a "move" onto the same value: see k_local_search
+        if (trace && lane == 0) trace[(size_t)row * moves + mv] = 2 * c + (go_up ? 1 : 0);
+
+        const float *hrow = H + (size_t)c * n;
+        const float two_dq = 2.0f * (q_old - q_new);
+        float h_cc = 0.0f, total = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < M8; ++i) {
+                const int e = s2 * M8 + i;
+                const float h = hrow[col[e]];
+                const float p = (q[e] - w[e]) * h;  // Q still holds the old value at column c
+                acc = i == 0 ? p : acc + p;
+                if (col[e] == c) {
+                    h_cc = h;
+                } else {
+                    const float f = two_dq * h;
+                    gu[e] = gu[e] + f * (cand_up(q[e], g) - q[e]);
+                    gd[e] = gd[e] + f * (cand_down(q[e], g) - q[e]);
+                }
+            }
+            // the leaf (8 accumulators = 8 lanes), then the 8 leaves of this register set
+#pragma unroll
+            for (int sh = 1; sh <= 32; sh <<= 1) acc = acc + __shfl_xor(acc, sh, 64);
+            total = s2 == 0 ? acc : total + acc;
+        }
+        const float ssum = 0.0f + total;  // (NumPy's reduction starts from 0 and adds the chunk's pairwise sum)
+        (void)h_cc;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            if (col[e] == c) {
+                const float hc = hrow[c];
+                const float d1u = cand_up(q_old, g) - q_old, d2u = cand_up(q_new, g) - q_new;
+                const float d1d = cand_down(q_old, g) - q_old, d2d = cand_down(q_new, g) - q_new;
+                const float hd = hdiag[c];
+                const float f = two_dq * hc;
+                float x = gu[e];
+                x = x + hd * (d1u * d1u - d2u * d2u);
+                x = x + (2.0f * ssum) * (d1u - d2u);
+                x = x + f * d2u;
+                gu[e] = x;
+                float y = gd[e];
+                y = y + hd * (d1d * d1d - d2d * d2d);
+                y = y + (2.0f * ssum) * (d1d - d2d);
+                y = y + f * d2d;
+                gd[e] = y;
+                q[e] = q_new;
+            }
+        }
+    }
+    if (trace && lane == 0)
+        for (; mv < moves; ++mv) trace[(size_t)row * moves + mv] = -1;
+
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int j = col[e];
+        Q[base + j] = q[e];
+        if (idx) idx[base + j] = (uint8_t)cb_index(q[e], g);
+        if (gains_mode) {
+            gains[2 * base + j] = gu[e];
+            gains[2 * base + n + j] = gd[e];
+        }
+    }
+}
+
 }  // namespace slk
 
 using namespace slk;
@@ -227,6 +357,35 @@ extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R,
         SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                       \
                 k_local_search<E><<<R, 256, lds, s>>>(W, Q, H, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode)); \
     } while (0)
+    // regular row lengths (8 or 16 leaves of m <= 128 elements, m % 8 == 0): one wave per row, no LDS, no barrier
+    {
+        int m = n, leaves = 1;
+        bool regular = true;
+        while (m > 128 && regular) {
+            regular = m % 2 == 0 && (m / 2) % 8 == 0;  // NumPy splits at (m / 2) rounded down to 8: only even halves keep the tree regular
+            m /= 2;
+            leaves *= 2;
+        }
+        // (measured, 10 moves: 3072 x 1024 135 -> 95 us, 4096 x 1024 170 -> 154, but 1024 x 1024 68 -> 80: with few rows either
+        // kernel is the latency of one move after the other, and the wave kernel's shuffles are LDS-crossbar permutes)
+        const int wave_opt = opt(OPT_NO_WAVE_SEARCH);  // 1: never, -1: whenever the row length allows (tests)
+        regular = regular && m % 8 == 0 && m >= 8 && (leaves == 8 || leaves == 16) && wave_opt <= 0 && (R >= 2048 || wave_opt < 0);
+        if (regular) {
+            const int m8 = m / 8, sets = leaves / 8;
+#define SLK_LSW(M8, S)                                                                                                  \
+    if (m8 == M8 && sets == S) {                                                                                        \
+        SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                           \
+                k_local_search_wave<M8, S><<<(R + 3) / 4, 256, 0, s>>>(W, Q, H, G, hdiag, R, n, g, moves, idx, trace, gains, \
+                                                                        gains_mode));                                  \
+        return SLK_OK;                                                                                                  \
+    }
+            SLK_LSW(16, 1)  // n = 1024
+            SLK_LSW(12, 1)  // n = 768
+            SLK_LSW(16, 2)  // n = 2048
+            SLK_LSW(12, 2)  // n = 1536
+#undef SLK_LSW
+        }
+    }
     if (ept <= 4) SLK_LS(4);
     else if (ept <= 8) SLK_LS(8);
     else if (ept <= 16) SLK_LS(16);

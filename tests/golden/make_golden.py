@@ -312,6 +312,9 @@ def pieces():
         st = Sleekit(lin)
         st.add_batch(torch.from_numpy(Xa[:128]))
         st.add_batch(torch.from_numpy(Xa[128:]).reshape(2, 86, 40))
+        # the statistics the reference holds before it quantizes (the same for the three presets): with THESE on the
+        # device the quantized weights must be the reference's bit for bit where no GEMM-ranked choice is involved
+        P["adapter/H_ref"], P["adapter/mean_ref"], P["adapter/count_ref"] = st.hessian.numpy().copy(), st.mean.numpy().copy(), np.int64(st.count)
         getattr(st, "quantize_" + preset)(bits)
         P[f"adapter/{preset}/weight"] = lin.weight.detach().numpy().copy()
         P[f"adapter/{preset}/bias"] = lin.bias.detach().numpy().copy()

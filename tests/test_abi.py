@@ -133,3 +133,19 @@ def test_interface_mirrors_reference_names():
     assert sig.parameters["damp"].default == 0.01 and sig.parameters["min_block_size"].default == 32
     sig = inspect.signature(scaling.quantize_with_scaling)
     assert [p for p in sig.parameters] == ["data", "scale", "quantizer", "H", "act_order", "damp", "nb_ls_moves"]
+
+
+def test_bench_workloads_are_the_baseline_configs():
+    """bench.py --config cfgN builds the layer streams SURVEY.md 8 names (counts from results/compare_3b.csv: 72 / 144 / 96
+    layers) with each config's codebook size, moves and Hessian correction."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    W = bench.WORKLOADS
+    assert [len(W[c]["block"]) * W[c]["blocks"] for c in ("cfg2", "cfg3", "cfg4", "cfg5")] == [72, 144, 96, 32]
+    assert (W["cfg2"]["levels"], W["cfg3"]["levels"], W["cfg4"]["levels"], W["cfg5"]["levels"]) == (8, 3, 8, 4)
+    assert W["cfg3"]["strip"] and W["cfg4"]["moves"] == 10 and not W["cfg2"]["moves"]
+    weights = {c: sum(r * n for r, n in W[c]["block"]) * W[c]["blocks"] for c in W}
+    assert weights["cfg2"] == 84934656 and weights["cfg3"] == weights["cfg4"] == 301989888 and weights["cfg5"] == 32 * 4096 * 11008

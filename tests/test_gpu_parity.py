@@ -705,6 +705,26 @@ def test_adapter_presets_end_to_end(amd, pieces, preset, bits):
     np.testing.assert_allclose(lin.bias.detach().cpu().numpy()[same_rows], pieces[f"adapter/{preset}/bias"][same_rows], rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("preset,bits", [("basic", 4), ("sleekit_light", 3)])
+def test_adapter_presets_from_the_reference_statistics(amd, pieces, preset, bits):
+    """The same presets with the REFERENCE's accumulated Hessian and mean placed on the device (so that the MFMA
+    accumulation's own rounding is out of the picture): `basic` (mse scale search, diag order) and `sleekit_light`
+    (diagonal-Hessian scale search, sqerr order, H - m m^T, damp 0.03) involve no choice ranked by a GEMM, so the
+    quantized weights must be the reference's bit for bit; the corrected bias is a float32 row sum (torch's order there)."""
+    lin = torch.nn.Linear(40, 24)
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(synth.make_weights(24, 40, 2032)))
+        lin.bias.copy_(torch.from_numpy((0.1 * synth.normal_grid(2032, 11, 1, 24)[0]).astype(np.float32)))
+    lin = lin.cuda()
+    st = amd.statistics.Sleekit(lin)
+    st.hessian.copy_(torch.from_numpy(pieces["adapter/H_ref"]))
+    st.mean.copy_(torch.from_numpy(pieces["adapter/mean_ref"]))
+    st.count = int(pieces["adapter/count_ref"])
+    getattr(st, "quantize_" + preset)(bits)
+    assert np.array_equal(lin.weight.detach().cpu().numpy(), pieces[f"adapter/{preset}/weight"]), preset
+    np.testing.assert_allclose(lin.bias.detach().cpu().numpy(), pieces[f"adapter/{preset}/bias"], rtol=1e-5, atol=1e-7)
+
+
 def test_compare_experiment_sequence(amd):
     """The call sequence of the reference's experiments/compare.py:54-131 (its five quantization recipes),
     run through the drop-in modules and through the oracle; the five reported errors must agree."""

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
 
         const float *hrow = H + (size_t)c * n;
         const float two_dq = 2.0f * (q_old - q_new);
-        float h_cc = 0.0f, total = 0.0f;
+        float h_cc = 0.0f, total = 0.0f;  // h_cc: H[c][c], met by the lane that owns column c
 #pragma unroll
         for (int s2 = 0; s2 < S; ++s2) {
             float acc = 0.0f;
@@ -283,11 +283,10 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
             total = s2 == 0 ? acc : total + acc;
         }
         const float ssum = 0.0f + total;  // (NumPy's reduction starts from 0 and adds the chunk's pairwise sum)
-        (void)h_cc;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             if (col[e] == c) {
-                const float hc = hrow[c];
+                const float hc = h_cc;
                 const float d1u = cand_up(q_old, g) - q_old, d2u = cand_up(q_new, g) - q_new;
                 const float d1d = cand_down(q_old, g) - q_old, d2d = cand_down(q_new, g) - q_new;
                 const float hd = hdiag[c];

@@ -16,6 +16,8 @@ The module is engine-agnostic: `backend` supplies factorize / run_rows, which le
 test-suite drive the same scheduling code over gloo with a stand-in backend.
 """
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -102,8 +104,6 @@ class HipBackend:
 
         self.engine, self.quantizer, self.overlap = engine, quantizer, overlap
         self.act_order, self.damp, self.moves, self.with_error = act_order, damp, nb_ls_moves, with_error
-        import os
-
         self.local_batch = int(os.environ.get("SLK_LOCAL_BATCH", self.local_batch))            # (measurement knobs)
         self.local_batch_cols = int(os.environ.get("SLK_LOCAL_BATCH_COLS", self.local_batch_cols))
 

@@ -349,6 +349,8 @@ LARGE = [
     (3072, 1024, 1009, 8, "diag", 0.01, 10, False),  # cfg4 (BLOOM-560M qkv) + 10 moves
     (1024, 4096, 1010, 8, "diag", 0.01, 10, False),  # cfg4 (BLOOM-560M 4h->h) + 10 moves
     (4096, 4096, 1011, 8, "diag", 0.01, 10, False),  # headline shape + 10 moves
+    (4096, 11008, 1012, 4, "diag", 0.01, 0, False),  # cfg5: a whole Llama-FFN layer, 2 bit (a minute of reference time)
+    (4096, 1024, 1013, 3, "diag", 0.01, 0, True),    # cfg3: OPT-350M fc1, 1.5 bit + bias-corrected Hessian
 ]
 
 

@@ -862,6 +862,18 @@ def test_cfg5_row_shard_11008(amd, large_cases):
     print("512x11008", _large(amd, c))
 
 
+def test_cfg5_full_layer_11008(amd, large_cases):
+    """BASELINE cfg5: a WHOLE 4096 x 11008 layer at 2 bit against the hash the real reference produced (its inputs made
+    on the device: same bytes as the host generator, test_device_generator_makes_the_same_bytes)."""
+    c = next(c for c in large_cases if (c["R"], c["n"]) == (4096, 11008))
+    L = synth.make_layer_device(c["R"], c["n"], c["seed"], torch.device("cuda"))
+    _layers[(c["R"], c["n"], c["seed"], ())] = {k: L[k].cpu().numpy() for k in ("W", "H", "mean", "scale")}
+    del L
+    torch.cuda.empty_cache()
+    print("4096x11008", _large(amd, c))
+    del _layers[(c["R"], c["n"], c["seed"], ())]
+
+
 def test_headline_properties_4096(amd):
     """Size-independent properties at the headline size: row shards are independent, indices
     decode to the returned values, re-blocking is (almost) a pure re-association."""

@@ -157,10 +157,15 @@ def main():
     weights_per_step = float(sum(R * n for R, n in shapes))
 
     # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: one loop stream; the batched rounds run on the factor streams)
-    # (on 8 ranks a rank factors ONE layer per round and runs the round's loop on that factor stream: two such chains in
-    # flight measured best -- 4.9 ms per step against 5.7 ... 6.8 with three, tools/micro_rank_of_n.py, NF = 1 ... 4)
-    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else ((3, 3) if launch_bound else ((2, 1) if world >= 8 else (3, 1)))
+    # (from 4 ranks up a rank factors one or two layers per step: TWO factor streams and the batched rounds on a loop
+    # stream of their own measured best -- one rank's step of the headline batch, tools/micro_rank_of_n.py with
+    # ROUNDS_ON_FS / NF / NL: N = 8: 4.3 ms against 4.7 with the rounds on the factor streams and 5.1 ... 5.4 with three
+    # factor streams; N = 4: 7.9 against 8.5 ... 9.8; N = 2 keeps three factor streams and rounds on them, 14.8 against 15.4)
+    few_factors = world >= 4
+    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else ((3, 3) if launch_bound else ((2, 1) if few_factors else (3, 1)))
     backend = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=streams)
+    if few_factors:
+        backend.rounds_on_factor_streams = False
 
     in_flight = []  # per enqueued step: events at the tail of its loop streams
 

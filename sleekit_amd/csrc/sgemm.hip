@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
 // would otherwise be split once per tile that uses it (32 times at n = 4096).
 __global__ __launch_bounds__(256) void k_split3(const float *__restrict__ x, const float *__restrict__ y, int rows, int n,
                                                 unsigned short *__restrict__ out, size_t plane,
-                                                const int *__restrict__ sym_flag, int swz) {
+                                                const int *__restrict__ sym_flag, int swz, int band_only) {
     if (sym_flag && sym_flag[0] <= 0) return;
     const int ksteps = n / 32;
     const size_t quads = plane / 4;  // groups of four consecutive k
@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void k_split3(const float *__restrict__ x, con
         const int k4 = (int)(e & 31), r = (int)((e >> 5) & 127);
         const size_t slab = e >> 12;                  // rb * ksteps + ks
         const int ks = (int)(slab % ksteps), rb = (int)(slab / ksteps);
+        // (a symmetric H whose error alone is wanted: tile column rb of the GEMM reads the k steps up to its diagonal
+        // band only, k < 128 (rb + 1) -- the other half of the plane is never looked at)
+        if (band_only && ks >= 4 * (rb + 1)) continue;
         const int row = min(rb * 128 + r, rows - 1);
         const size_t src = (size_t)row * n + ks * 32 + k4;
         float4_t v = *reinterpret_cast<const float4_t *>(x + src);
@@ -624,10 +627,11 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
         SLK_LDS_OPT_IN(k_error_tiles_bf16<true>, sizeof(TileBf16DmaSmem));
         const int dma = !opt(OPT_NO_BF16_DMA);  // operands to LDS by global_load_lds (swizzled planes)
         SLK_RUN("error_split", 0, 14.0 * R * n, s,
-                k_split3<<<2048, 256, 0, s>>>(W, Q, R, n, Dp, d_plane, batch == 1 && !asym_mode ? sym : nullptr, dma));
+                k_split3<<<2048, 256, 0, s>>>(W, Q, R, n, Dp, d_plane, batch == 1 && !asym_mode ? sym : nullptr, dma, 0));
         for (int b = 0; b < batch; ++b) {
             SLK_RUN("error_split", 0, 10.0 * n * n, s,
-                    k_split3<<<2048, 256, 0, s>>>(Hs[b], nullptr, n, n, Hp + (size_t)b * 3 * n * n, (size_t)n * n, sym + b, dma));
+                    k_split3<<<2048, 256, 0, s>>>(Hs[b], nullptr, n, n, Hp + (size_t)b * 3 * n * n, (size_t)n * n, sym + b, dma,
+                                                  G == nullptr));
             if (asym_mode)  // (returns at once when the flag says symmetric)
                 SLK_RUN("error_split_t", 0, 0, s,
                         k_split3_transposed<<<dim3(n / T32, n / 32), 256, 0, s>>>(Hs[b], n, n, 0, n, Hp + (size_t)b * 3 * n * n,

@@ -54,7 +54,7 @@ def main():
     weights = float(sum(R * n for R, n in shapes))
     for N in Ns:
         nl = int(os.environ.get("NL", "0")) or 1  # bench.py's default
-        nf = int(os.environ.get("NF", "0")) or (2 if N >= 8 else 3)  # bench.py's default
+        nf = int(os.environ.get("NF", "0")) or (2 if N >= 4 else 3)  # bench.py's default
         backend = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=(nf, nl))
         calls = {"round": 0, "layers_in_rounds": 0, "rows": 0}
         run_round, run_rows = backend.run_round, backend.run_rows
@@ -69,6 +69,9 @@ def main():
             return run_rows(*a)
 
         backend.run_round, backend.run_rows = counted_round, counted_rows
+        backend.rounds_on_factor_streams = N < 4  # bench.py's default
+        if os.environ.get("ROUNDS_ON_FS"):
+            backend.rounds_on_factor_streams = os.environ["ROUNDS_ON_FS"] != "0"
         sdist.rehearse = (0, N) if N > 1 else None
 
         def step():

@@ -34,8 +34,9 @@ def main():
     layers[1]["H"] = layers[1]["H"].clone()
     layers[1]["H"][2, 5] += 0.125  # not symmetric: that layer's error takes the float32 kernel inside the batch
     calls = {"round": 0, "rows": 0}
-    for overlap, moves in (((2, 2), 0), (False, 0), ((2, 2), 6)):
+    for overlap, moves, on_fs in (((2, 2), 0, True), (False, 0, True), ((2, 2), 6, True), ((2, 1), 0, False)):
         backend = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=overlap)
+        backend.rounds_on_factor_streams = on_fs  # (False: the rounds on a loop stream of their own, bench.py from 4 ranks up)
         run_round, run_rows = backend.run_round, backend.run_rows
         backend.run_round = lambda *a: (calls.__setitem__("round", calls["round"] + 1), run_round(*a))[1]
         backend.run_rows = lambda *a: (calls.__setitem__("rows", calls["rows"] + 1), run_rows(*a))[1]
@@ -51,7 +52,7 @@ def main():
             np.testing.assert_allclose(sh["row_err"].cpu().numpy(), err[lo:hi].cpu().numpy(), rtol=1e-5)
             assert int(sh["info"].item()) == 0
     # bucketed by shape: rounds (0, 3), (1, 4) and the ragged (2, 5) -- padded to whole tiles -- batched; (6) alone
-    assert calls["round"] == 3 * 3 and calls["rows"] == 3 * 1, calls
+    assert calls["round"] == 4 * 3 and calls["rows"] == 4 * 1, calls
     dist.barrier()
     dist.destroy_process_group()
     print(f"DIST_ROUND_OK rank {rank}", flush=True)

@@ -200,24 +200,31 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 // the 8 leaves of a register set the shuffles 8, 16, 32 (NumPy's halving), two sets one more add.  Four rows per
 // workgroup and no barrier in the move: 135 -> 95 us for 3072 x 1024 with 10 moves (taken from 2048 rows up, see the
 // dispatch below).  Same arithmetic in the same order: bit-equal to k_local_search.
-template <int M8, int S>
+// WAVES = 4: the same with ONE ROW per 256-thread workgroup, for trees of 32 or 64 leaves (n = 3072, 4096, 6144, 8192):
+// thread t, register set s holds chain t + 256 s; a wave's 8 leaves are a sub-tree of NumPy's recursion, the four waves'
+// sums meet in LDS as (T0 + T1) + (T2 + T3).  Two barriers per move (best move, sum) against the general kernel's five,
+// and no staging of the products: 684 -> 532 us for 4096 x 4096 with 10 moves, 242 -> 184 for 1024 x 4096.
+template <int M8, int S, int WAVES>
 __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restrict__ W, float *__restrict__ Q,
                                                            const float *__restrict__ H, const float *__restrict__ G,
                                                            const float *__restrict__ hdiag, int R, int n, Grid g, int moves,
                                                            uint8_t *__restrict__ idx, int *__restrict__ trace,
                                                            float *__restrict__ gains, int gains_mode) {
     constexpr int EPT = M8 * S;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= R) return;  // (whole waves: no barrier anywhere below)
+    __shared__ Best red_up[4], red_dn[4];
+    __shared__ float red_s[2][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = WAVES == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
+    if (row >= R) return;  // (WAVES == 1: whole waves, and no barrier anywhere below; WAVES == 4: the whole workgroup)
     const int m = 8 * M8;
+    const int tr = WAVES == 1 ? lane : threadIdx.x;  // thread within the row
     const size_t base = (size_t)row * n;
     const float NEG = -__builtin_huge_valf();
     int col[EPT];
 #pragma unroll
     for (int s2 = 0; s2 < S; ++s2)
 #pragma unroll
-        for (int i = 0; i < M8; ++i) col[s2 * M8 + i] = ((lane >> 3) + 8 * s2) * m + (lane & 7) + 8 * i;
+        for (int i = 0; i < M8; ++i) col[s2 * M8 + i] = ((tr >> 3) + 8 * WAVES * s2) * m + (tr & 7) + 8 * i;
 
     float w[EPT], q[EPT], gu[EPT], gd[EPT];
 #pragma unroll
@@ -248,6 +255,15 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
         }
         bu = wave_best(bu);
         bd = wave_best(bd);
+        if (WAVES > 1) {
+            if (lane == 0) {  // (the previous move's readers of these slots have passed the barrier of its sum)
+                red_up[wv] = bu;
+                red_dn[wv] = bd;
+            }
+            __syncthreads();
+            bu = better(better(red_up[0], red_up[1]), better(red_up[2], red_up[3]));
+            bd = better(better(red_dn[0], red_dn[1]), better(red_dn[2], red_dn[3]));
+        }
         const bool go_up = (bu.v > bd.v) && (bu.v > 0.0f);
         const bool go_down = !go_up && (bd.v > 0.0f);
         if (!go_up && !go_down) break;
@@ -255,7 +271,7 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
         const float q_old = go_up ? bu.q : bd.q;
         const float q_new = go_up ? cand_up(q_old, g) : cand_down(q_old, g);
         if (q_new == q_old) break;  // a "move" onto the same value: see k_local_search
-        if (trace && lane == 0) trace[(size_t)row * moves + mv] = 2 * c + (go_up ? 1 : 0);
+        if (trace && tr == 0) trace[(size_t)row * moves + mv] = 2 * c + (go_up ? 1 : 0);
 
         const float *hrow = H + (size_t)c * n;
         const float two_dq = 2.0f * (q_old - q_new);
@@ -280,7 +296,13 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
             // the leaf (8 accumulators = 8 lanes), then the 8 leaves of this register set
 #pragma unroll
             for (int sh = 1; sh <= 32; sh <<= 1) acc = acc + __shfl_xor(acc, sh, 64);
+            if (WAVES > 1 && lane == 0) red_s[s2][wv] = acc;  // this wave's 8 leaves of the set
             total = s2 == 0 ? acc : total + acc;
+        }
+        if (WAVES > 1) {
+            __syncthreads();
+            total = (red_s[0][0] + red_s[0][1]) + (red_s[0][2] + red_s[0][3]);
+            if (S > 1) total = total + ((red_s[1][0] + red_s[1][1]) + (red_s[1][2] + red_s[1][3]));
         }
         const float ssum = 0.0f + total;  // (NumPy's reduction starts from 0 and adds the chunk's pairwise sum)
 #pragma unroll
@@ -305,7 +327,7 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
             }
         }
     }
-    if (trace && lane == 0)
+    if (trace && tr == 0)
         for (; mv < moves; ++mv) trace[(size_t)row * moves + mv] = -1;
 
 #pragma unroll
@@ -368,22 +390,27 @@ extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R,
         // (measured, 10 moves: 3072 x 1024 135 -> 95 us, 4096 x 1024 170 -> 154, but 1024 x 1024 68 -> 80: with few rows either
         // kernel is the latency of one move after the other, and the wave kernel's shuffles are LDS-crossbar permutes)
         const int wave_opt = opt(OPT_NO_WAVE_SEARCH);  // 1: never, -1: whenever the row length allows (tests)
-        regular = regular && m % 8 == 0 && m >= 8 && (leaves == 8 || leaves == 16) && wave_opt <= 0 && (R >= 2048 || wave_opt < 0);
-        if (regular) {
-            const int m8 = m / 8, sets = leaves / 8;
-#define SLK_LSW(M8, S)                                                                                                  \
-    if (m8 == M8 && sets == S) {                                                                                        \
+        regular = regular && m % 8 == 0 && m >= 8 && wave_opt <= 0;
+        const int m8 = m / 8;
+#define SLK_LSW(M8, S, WAVES, LEAVES)                                                                                   \
+    if (regular && m8 == M8 && leaves == LEAVES) {                                                                      \
         SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                           \
-                k_local_search_wave<M8, S><<<(R + 3) / 4, 256, 0, s>>>(W, Q, H, G, hdiag, R, n, g, moves, idx, trace, gains, \
-                                                                        gains_mode));                                  \
+                k_local_search_wave<M8, S, WAVES><<<WAVES == 1 ? (R + 3) / 4 : R, 256, 0, s>>>(                         \
+                    W, Q, H, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode));                                 \
         return SLK_OK;                                                                                                  \
     }
-            SLK_LSW(16, 1)  // n = 1024
-            SLK_LSW(12, 1)  // n = 768
-            SLK_LSW(16, 2)  // n = 2048
-            SLK_LSW(12, 2)  // n = 1536
-#undef SLK_LSW
+        if (R >= 2048 || wave_opt < 0) {  // a wave per row: 8 or 16 leaves
+            SLK_LSW(16, 1, 1, 8)   // n = 1024
+            SLK_LSW(12, 1, 1, 8)   // n = 768
+            SLK_LSW(16, 2, 1, 16)  // n = 2048
+            SLK_LSW(12, 2, 1, 16)  // n = 1536
         }
+        // a workgroup per row, a chain per thread: 32 or 64 leaves
+        SLK_LSW(16, 1, 4, 32)  // n = 4096
+        SLK_LSW(12, 1, 4, 32)  // n = 3072
+        SLK_LSW(16, 2, 4, 64)  // n = 8192
+        SLK_LSW(12, 2, 4, 64)  // n = 6144
+#undef SLK_LSW
     }
     if (ept <= 4) SLK_LS(4);
     else if (ept <= 8) SLK_LS(8);

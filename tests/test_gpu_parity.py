@@ -594,11 +594,12 @@ def test_local_search_standalone(amd):
         assert (np.abs(got.astype(np.float64) - want) <= 4.0 * 2.0 ** -24 * terms + 1e-30).all()
 
 
-@pytest.mark.parametrize("n", [768, 1024, 1536, 2048])
+@pytest.mark.parametrize("n", [768, 1024, 1536, 2048, 3072, 4096, 6144, 8192])
 def test_local_search_wave_kernel_is_the_workgroup_kernel(amd, n):
-    """Row lengths whose NumPy summation tree is 8 or 16 regular leaves take the wave-per-row search kernel (no LDS, no
-    barrier): same moves, same final values, same carried gains as the workgroup-per-row kernel, bit for bit -- and as
-    the oracle on the narrowest one."""
+    """Row lengths whose NumPy summation tree is regular take the chain-per-lane search kernels -- 8 or 16 leaves: a wave
+    per row, no LDS, no barrier; 32 or 64 leaves: a workgroup per row, two barriers per move -- with the same moves, the
+    same final values and the same carried gains as the general workgroup-per-row kernel, bit for bit; and as the
+    oracle on the narrowest one."""
     R = 70  # (not a multiple of the 4 rows per workgroup)
     L = synth.make_layer_device(R, n, 4200 + n, torch.device("cuda"))
     cb = amd.codebook.UniformCodebook(8, -1, 1)

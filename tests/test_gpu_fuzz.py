@@ -91,3 +91,39 @@ def test_blockings_against_oracle(amd, seed):
     amd.obq._quantize_opt_block(Q1, E1, U, cb, mb, nb)
     assert np.array_equal(Q1, Q0), (R, n, mb, nb)
     np.testing.assert_allclose(E1, E0, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_batched_rounds_against_single_layers(amd, seed):
+    """Random rounds of same-shaped small layers through the batched factorisation + stacked loop of one rank
+    (sleekit_amd.dist, slk_*_batch) against the same layers one by one: bit-equal values and indices, whatever the shape
+    (ragged rows, widths that are not a multiple of the factor's 64-column tiles), the codebook size and the damping."""
+    import torch
+
+    from sleekit_amd import dist as sdist
+
+    rng = np.random.default_rng(900 + seed)
+    B = int(rng.choice([2, 3, 5, 8]))
+    R = int(rng.choice([7, 16, 50, 128, 130]))
+    n = int(rng.choice([33, 64, 100, 172, 200, 320]))
+    levels = int(rng.choice([2, 3, 4, 8, 16]))
+    damp = float(rng.choice([0.01, 0.03, 0.1]))
+    moves = int(rng.choice([0, 0, 4]))
+    order = str(rng.choice(["diag", "none"]))
+    cb = amd.codebook.UniformCodebook(levels, -1, 1)
+    layers = []
+    for b in range(B):
+        T = 2 * n + 8
+        X = rng.standard_normal((T, n)) * (0.5 + 2.0 * rng.random(n))
+        H = (X.T @ X / T).astype(np.float32)
+        H = ((H + H.T) * np.float32(0.5)).astype(np.float32)
+        W = (rng.standard_normal((R, n)) * 0.05).astype(np.float32)
+        scale = (np.abs(W).max(axis=1) * np.float32(0.55) + np.float32(1e-6)).astype(np.float32)
+        layers.append({k: torch.from_numpy(v).cuda() for k, v in (("W", W), ("H", H), ("scale", scale))})
+    be = sdist.HipBackend(cb, order, damp, moves, with_error=True)
+    shards = sdist.quantize_stream(layers, be)
+    torch.cuda.synchronize()
+    for lay, sh in zip(layers, shards):
+        res = amd.engine.quantize_layer(lay["W"], lay["H"], cb, lay["scale"], order, damp, moves)
+        assert torch.equal(sh["Q"], res.Q) and torch.equal(sh["idx"], res.idx), (B, R, n, levels, damp, moves, order)
+        assert int(sh["info"].item()) == 0

@@ -47,6 +47,8 @@ extern "C" {
 #define SLK_CB_INDEX 1 /* uint8 out (levels <= 256) */
 #define SLK_CB_UP 2    /* float32 out */
 #define SLK_CB_DOWN 3  /* float32 out */
+#define SLK_CB_INDEX16 4 /* uint16 out (levels <= 65536): UniformCodebook above 256 entries, codebook.py:50-54 */
+#define SLK_CB_INDEX32 5 /* uint32 out */
 
 /* column orders, slk_hessian_prepare `order_mode` (obq.py:58-86) */
 #define SLK_ORDER_NONE 0

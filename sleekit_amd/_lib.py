@@ -20,7 +20,7 @@ if not os.path.exists(LIB_PATH):
 lib = ctypes.CDLL(LIB_PATH)
 
 OK, E_ARG, E_NOT_PD, E_HIP, E_WS = 0, -1, -2, -3, -4
-CB_VALUE, CB_INDEX, CB_UP, CB_DOWN = 0, 1, 2, 3
+CB_VALUE, CB_INDEX, CB_UP, CB_DOWN, CB_INDEX16, CB_INDEX32 = 0, 1, 2, 3, 4, 5
 ORDER_NONE, ORDER_DIAG, ORDER_ERR, ORDER_SQERR, ORDER_KEYS = 0, 1, 2, 3, 4
 ORDER_MODES = {"none": ORDER_NONE, "diag": ORDER_DIAG, "err": ORDER_ERR, "sqerr": ORDER_SQERR}
 

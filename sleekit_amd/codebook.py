@@ -26,9 +26,14 @@ class DeviceCodebook:
     def _apply(self, data, what):
         x = dev.to_device(data, torch.float32)
         if what == _lib.CB_INDEX:
-            if len(self) > 256:
-                raise NotImplementedError("device indices are uint8: codebooks above 256 entries are not on the path")
-            out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+            # the narrowest unsigned type that holds every index, like the reference (codebook.py:50-54); torch has no
+            # arithmetic on uint16 / uint32, so a device tensor gets int16 / int32 storage viewed as the unsigned type
+            if len(self) <= 2**8:
+                out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+            elif len(self) <= 2**16:
+                what, out = _lib.CB_INDEX16, torch.empty(x.shape, dtype=torch.uint16, device=x.device)
+            else:
+                what, out = _lib.CB_INDEX32, torch.empty(x.shape, dtype=torch.uint32, device=x.device)
         else:
             out = torch.empty_like(x)
         levels, lo, hi, table = self._abi()
@@ -40,7 +45,7 @@ class DeviceCodebook:
         return dev.like_input(out, data)
 
     def quantize_index(self, data):
-        """Index of the nearest codebook value (uint8)."""
+        """Index of the nearest codebook value (uint8, or uint16 / uint32 for codebooks above 256 / 65536 entries)."""
         return self._apply(data, _lib.CB_INDEX)
 
     def quantize_value(self, data):

@@ -34,6 +34,10 @@ __global__ __launch_bounds__(256) void k_codebook(const float *__restrict__ x, s
             static_cast<float *>(out)[i] = cb_value(v, g);
         } else if (WHAT == SLK_CB_INDEX) {
             static_cast<uint8_t *>(out)[i] = (uint8_t)cb_index(v, g);
+        } else if (WHAT == SLK_CB_INDEX16) {
+            static_cast<uint16_t *>(out)[i] = (uint16_t)cb_index(v, g);
+        } else if (WHAT == SLK_CB_INDEX32) {
+            static_cast<uint32_t *>(out)[i] = (uint32_t)cb_index(v, g);
         } else if (WHAT == SLK_CB_UP) {
             static_cast<float *>(out)[i] = cb_up(v, g);
         } else {
@@ -155,8 +159,10 @@ const char *slk_last_error(void) { return g_error; }
 int slk_codebook_apply(const float *x, size_t count, int levels, double lo, double hi, const float *table, int what,
                        void *out, slk_stream_t stream) {
     SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
-    SLK_REQUIRE(what >= 0 && what <= 3, "unknown codebook map %d", what);
+    SLK_REQUIRE(what >= 0 && what <= 5, "unknown codebook map %d", what);
     SLK_REQUIRE(what != SLK_CB_INDEX || levels <= 256, "uint8 indices need levels <= 256");
+    SLK_REQUIRE(what != SLK_CB_INDEX16 || levels <= 65536, "uint16 indices need levels <= 65536");
+    SLK_REQUIRE(table == nullptr || levels <= 256, "general codebooks hold at most 256 entries");
     if (count == 0) return SLK_OK;
     SLK_REQUIRE(x && out, "null pointer");
     const Grid g = make_grid(levels, lo, hi, table);
@@ -167,6 +173,8 @@ int slk_codebook_apply(const float *x, size_t count, int levels, double lo, doub
         case SLK_CB_VALUE: SLK_RUN("codebook_apply", 0, bytes, s, k_codebook<SLK_CB_VALUE><<<blocks, 256, 0, s>>>(x, count, g, out)); break;
         case SLK_CB_INDEX: SLK_RUN("codebook_apply", 0, bytes, s, k_codebook<SLK_CB_INDEX><<<blocks, 256, 0, s>>>(x, count, g, out)); break;
         case SLK_CB_UP: SLK_RUN("codebook_apply", 0, bytes, s, k_codebook<SLK_CB_UP><<<blocks, 256, 0, s>>>(x, count, g, out)); break;
+        case SLK_CB_INDEX16: SLK_RUN("codebook_apply", 0, bytes, s, k_codebook<SLK_CB_INDEX16><<<blocks, 256, 0, s>>>(x, count, g, out)); break;
+        case SLK_CB_INDEX32: SLK_RUN("codebook_apply", 0, bytes, s, k_codebook<SLK_CB_INDEX32><<<blocks, 256, 0, s>>>(x, count, g, out)); break;
         default: SLK_RUN("codebook_apply", 0, bytes, s, k_codebook<SLK_CB_DOWN><<<blocks, 256, 0, s>>>(x, count, g, out)); break;
     }
     return SLK_OK;

@@ -283,21 +283,22 @@ class HipBackend:
                 if scaled:
                     sc[b, :rows].copy_(lay["scale"][lo:hi])
         cb = eng.require_uniform(self.quantizer)
+        want_idx = cb[0] <= 256  # (the kernels emit uint8 indices)
         if self.moves > 0:
             # local search works in the scaled domain (engine.quantize_layer): scaled copy in, one search per layer
             # (a workgroup per row each: already wide), de-scale on the way out
             Ws = eng.rows_divide(W.view(B * Rp, n), sc.reshape(-1)).view(B, Rp, n) if sc is not None else W
-            Q, idx = eng.run_loop_batch(Ws, None, order, U, cb, 32, 8)
+            Q, idx = eng.run_loop_batch(Ws, None, order, U, cb, 32, 8, want_idx=want_idx)
             for b, lay in enumerate(round_layers):
-                eng.local_search(Ws[b, :rows], Q[b, :rows], lay["H"], cb, self.moves, idx[b, :rows])
+                eng.local_search(Ws[b, :rows], Q[b, :rows], lay["H"], cb, self.moves, idx[b, :rows] if want_idx else None)
             if sc is not None:
                 Q = eng.rows_divide(Q.view(B * Rp, n), sc.reshape(-1), invert=True).view(B, Rp, n)
         else:
-            Q, idx = eng.run_loop_batch(W, sc, order, U, cb, 32, 8, unscale=sc is not None)
+            Q, idx = eng.run_loop_batch(W, sc, order, U, cb, 32, 8, want_idx=want_idx, unscale=sc is not None)
         err = None
         if self.with_error:
             err = eng.row_errors_batch(W, Q, [lay["H"] for lay in round_layers], known)
-        return [dict(Q=Q[b, :rows], idx=idx[b, :rows], row_err=None if err is None else err[b, :rows], rows=(lo, hi),
+        return [dict(Q=Q[b, :rows], idx=idx[b, :rows] if want_idx else None, row_err=None if err is None else err[b, :rows], rows=(lo, hi),
                      info=info[b:b + 1]) for b in range(B)]
 
 

@@ -64,9 +64,10 @@ def require_uniform(quantizer):
             "sleekit_amd runs UniformCodebook / Codebook quantizers on the GPU and has no CPU fallback for arbitrary "
             f"callables (got {type(quantizer).__name__})"
         )
-    if len(quantizer) > 256:
-        raise NotImplementedError("codebooks above 256 entries are not on the accelerated path")
-    return quantizer._abi()
+    abi = quantizer._abi()
+    if len(quantizer) > 256 and abi[3] is not None:
+        raise NotImplementedError("general (table) codebooks on the device hold at most 256 entries")
+    return abi
 
 
 class LayerResult:
@@ -274,6 +275,8 @@ def quantize_layer(
     assert H.shape[0] == W.shape[1]
     assert min_block_size >= 1
     cb_abi = require_uniform(quantizer)
+    if cb_abi[0] > 256:
+        want_idx = False  # (the kernels emit uint8 indices; wider ones come from quantizer.quantize_index on the values)
     mode = order_mode_code(act_order)
     R, n = W.shape
     res = LayerResult()

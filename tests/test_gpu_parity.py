@@ -66,6 +66,24 @@ def test_codebook_maps_bit_exact(amd, pieces, levels):
         assert got.dtype == want.dtype and np.array_equal(got, want), (levels, name)
 
 
+@pytest.mark.parametrize("levels", [257, 1024, 65536, 70000])
+def test_codebooks_above_256_entries(amd, pieces, levels):
+    """codebook.py:50-54: indices widen to uint16 / uint32; the maps and a whole GPTQ layer (values; indices from the map)
+    against the oracle, bit for bit."""
+    x = pieces["cb/x"]
+    cb, g = amd.codebook.UniformCodebook(levels, -1, 1), grid.UniformGrid(levels, -1, 1)
+    for name, fn in (("value", g.value), ("index", g.index), ("up", g.up), ("down", g.down)):
+        got, want = getattr(cb, "quantize_" + name)(x), fn(x.copy())
+        assert got.dtype == want.dtype and np.array_equal(got, want), (levels, name)
+    if levels <= 1024:
+        L = layer(64, 96, 2001)
+        want = scaling_ref.quantize_scaled(L["W"], L["scale"], g, L["H"], "diag", 0.01, 3 if levels == 1024 else 0)
+        got = amd.scaling.quantize_with_scaling(L["W"], L["scale"], cb, L["H"], nb_ls_moves=3 if levels == 1024 else 0)
+        assert np.array_equal(got, want)
+        assert np.array_equal(cb.quantize_index(amd.scaling.apply_scaling(got, L["scale"], 0)),
+                              g.index(scaling_ref.divide_rows(want, L["scale"], 0)))
+
+
 def test_float32_divide_is_ieee(amd):
     """apply_scaling must be a correctly rounded divide, incl. subnormal results (scaling.py:21-25, 80)."""
     rng = np.random.default_rng(3)

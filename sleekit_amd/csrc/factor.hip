@@ -382,9 +382,9 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
 
     // Look-ahead over the outer blocks (below): a helper stream and events.  For ONE factorisation at a time it takes
     // 0.6 ms off a 4096-column layer (6.2 -> 5.6 ms end to end); with several factorisations in flight on streams of
-    // their own (sleekit_amd.dist) the extra streams push the process past its 8 hardware queues, streams start sharing
-    // queues and stop overlapping (4830 -> 3560 Mweights/s on one rank, 4.7 -> 7.3 ms per step of a rank of 8).  So it is
-    // a switch, off by default, which the single-layer API turns on (sleekit_amd/engine.py: quantize_layer).
+    // their own (sleekit_amd.dist) the chip is full already and the split launches and event joins only cost
+    // (4850 -> 3560 Mweights/s on one rank whatever GPU_MAX_HW_QUEUES is, 4.7 -> 7.3 ms per step of a rank of 8).  So it
+    // is a switch, off by default, which the single-layer API turns on (sleekit_amd/engine.py: quantize_layer).
     Helper helper{};
     const bool lookahead = opt(OPT_LOOKAHEAD) && nt >= LOOKAHEAD_MIN_TILES + OUTER / TILE && nt / (OUTER / TILE) < HELPER_EVENTS / 2;
     if (lookahead) SLK_HIP(helper_for(s, &helper));

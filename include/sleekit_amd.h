@@ -61,10 +61,11 @@ extern "C" {
 typedef void *slk_stream_t;
 
 /* Library / device ---------------------------------------------------------
- * slk_abi_version: 4.  History: 2 = every quantizing entry takes (levels, lo, hi, table); 3 adds the batch forms
+ * slk_abi_version: 5.  History: 2 = every quantizing entry takes (levels, lo, hi, table); 3 adds the batch forms
  * (slk_gptq_quantize_batch, slk_row_errors_batch, slk_workspace_bytes_batch) and slk_symmetry_flag; 4 adds the
  * `trace` and `gains` arguments of slk_local_search, slk_set_option / slk_get_option and the batched factorisation
- * (slk_hessian_prepare_batch, slk_chol_inverse_upper_batch, slk_factor_workspace_bytes_batch).                 */
+ * (slk_hessian_prepare_batch, slk_chol_inverse_upper_batch, slk_factor_workspace_bytes_batch); 5 adds codebook training
+ * (slk_codebook_stats, slk_sort_f32, slk_unique_f32).                                                          */
 int slk_abi_version(void);
 const char *slk_last_error(void);
 /* Run-time switches between code paths that give the same results (the tests hold them to that) or that shape a
@@ -83,6 +84,28 @@ size_t slk_workspace_bytes(int R, int n);
  *     out[i] = map(x[i]); float32 arithmetic, IEEE divide, round-half-even.    */
 int slk_codebook_apply(const float *x, size_t count, int levels, double lo, double hi, const float *table,
                        int what, void *out, slk_stream_t stream);
+
+/* Codebook TRAINING (Lloyd-Max; §8f row 4's other half): what one round of Codebook.improve / centroids /
+ * probabilities / mse reads off the data  (sleekit/codebook.py:190-267), in one pass:
+ *     counts[k] = #{i : index(x[i]) == k}                      (np.bincount of quantize_index)
+ *     sums[k]   = sum of those x[i], float64                   (-> centroid = sums / counts)
+ *     *sqerr    = sum_i (x[i] - value(x[i]))^2, the difference in float32 and the sum in float64  (-> mse = sqerr / count)
+ * for a codebook of 1..256 entries (a general one may hold a single value: every x falls in bin 0).
+ * by_position != 0: the "bin" of x[i] is the part of np.array_split(x, levels) that POSITION i falls in, the codebook
+ * is ignored and *sqerr = 0: the part means of Codebook.equiprobable (codebook.py:327-331) on sorted data.
+ * Results do not depend on scheduling: integer counts, sums in 64-bit fixed point scaled by max|x| (exact to
+ * max|x| * 2^-(62 - ceil(log2 count))), sqerr over a fixed tree.  count < 2^31.  Device outputs; workspace of
+ * slk_codebook_stats_workspace_bytes().                                                                          */
+size_t slk_codebook_stats_workspace_bytes(void);
+int slk_codebook_stats(const float *x, size_t count, int levels, double lo, double hi, const float *table, int by_position,
+                       long long *counts, double *sums, double *sqerr, void *workspace, size_t ws_bytes, slk_stream_t stream);
+/* np.sort / np.unique of float32 data on the device, the first step of lloyd_max and of its two initialisations
+ * (codebook.py:283, 327, 356).  `out` must not alias the input; *n_out (device) receives the number of distinct
+ * values.  Workspace of slk_sort_workspace_bytes(count) serves either call.                                       */
+size_t slk_sort_workspace_bytes(size_t count);
+int slk_sort_f32(const float *x, size_t count, float *out, void *workspace, size_t ws_bytes, slk_stream_t stream);
+int slk_unique_f32(const float *sorted, size_t count, float *out, int *n_out, void *workspace, size_t ws_bytes,
+                   slk_stream_t stream);
 
 /* a14 apply_scaling on axis 0  (sleekit/scaling.py:21-25, 73, 80)
  *     invert == 0: out[r][j] = x[r][j] / scale[r]

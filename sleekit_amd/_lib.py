@@ -39,6 +39,11 @@ PROTOTYPES = {
     "slk_hessian_strip_mean": (c_int, [P, P, c_int, P, P]),
     "slk_hessian_patch_dead": (c_int, [P, P, c_int, c_int, P, c_size_t, P]),
     "slk_hessian_accumulate": (c_int, [P, P, P, c_int, c_int, c_longlong, P, c_size_t, P]),
+    "slk_codebook_stats_workspace_bytes": (c_size_t, []),
+    "slk_codebook_stats": (c_int, [P, c_size_t, c_int, c_double, c_double, P, c_int, P, P, P, P, c_size_t, P]),
+    "slk_sort_workspace_bytes": (c_size_t, [c_size_t]),
+    "slk_sort_f32": (c_int, [P, c_size_t, P, P, c_size_t, P]),
+    "slk_unique_f32": (c_int, [P, c_size_t, P, P, P, c_size_t, P]),
     "slk_column_miss": (c_int, [P, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P]),
     "slk_hessian_prepare": (c_int, [P, c_int, c_float, c_int, P, P, P, P, c_size_t, P]),
     "slk_inverse_diag_keys": (c_int, [P, P, c_int, c_float, c_int, P, P, c_size_t, P]),

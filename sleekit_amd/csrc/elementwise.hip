@@ -152,7 +152,7 @@ using namespace slk;
 
 extern "C" {
 
-int slk_abi_version(void) { return 4; }
+int slk_abi_version(void) { return 5; }
 
 const char *slk_last_error(void) { return g_error; }
 

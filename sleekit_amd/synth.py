@@ -72,6 +72,13 @@ def make_weights(R, n, seed):
     return (0.02 * normal_grid(seed, 1, R, n)).astype(np.float32)
 
 
+def make_samples(count, seed, dtype=np.float32):
+    """1-D data to fit a codebook to: ~N(0, 1) with every 97th sample stretched by 4 (a heavy tail)."""
+    z = normal_grid(seed, 8, 1, count)[0]
+    z[::97] *= 4.0
+    return z.astype(dtype)
+
+
 def _channel_params(n, seed):
     gain = 0.5 + 2.0 * uniform_grid(seed, 2, 1, n)[0]
     hot = (hash_grid(seed, 3, 1, 20)[0] % np.uint64(n)).astype(np.int64)

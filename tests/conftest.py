@@ -39,6 +39,11 @@ def ls_traces():
     return np.load(os.path.join(GOLDEN, "ls_traces.npz"))
 
 
+@pytest.fixture(scope="session")
+def codebook_fit():
+    return np.load(os.path.join(GOLDEN, "codebook_fit.npz"))
+
+
 def parse_case(name):
     """'r64_n96_s2001_N8_diag_ls10[_strip_d0.03]' -> dict."""
     p = name.split("_")

@@ -12,6 +12,8 @@ reference's outputs:
     small_cases.npz   full outputs (u8 indices, order, row errors, ...) of small layers
     pieces.npz        known-answer vectors of the helper functions on the path
     large_cases.json  SHA-256 of indices + float32 errors of BASELINE-sized layers
+    codebook_fit.npz  known answers of the codebook training functions (equiprobable start, Lloyd-Max rounds, final
+                      codebooks with and without the entropy term, drawn starts, empty bins)
     ls_traces.npz     for every case with local-search moves: the reference's sequence of moves and how close each
                       decision was, for the rows that came near a tie (oracle/obq_ref.py: move_record), plus a
                       per-row hash of the indices of the large cases -- what lets a parity test PROVE that a row
@@ -377,12 +379,62 @@ def large_cases(selected=None):
     return out
 
 
+CODEBOOK_FIT_CASES = [  # (name, count, seed, dtype, size, lagrange_mult)
+    ("f32_4", 20000, 31, "float32", 4, 0.0),
+    ("f32_8", 20000, 31, "float32", 8, 0.0),
+    ("f32_16", 20000, 31, "float32", 16, 0.0),
+    ("f32_8_entropy", 20000, 31, "float32", 8, 0.05),
+    ("f32_16_entropy", 20000, 31, "float32", 16, 0.3),
+    ("f64_8", 5000, 32, "float64", 8, 0.0),
+    ("f32_200", 50000, 33, "float32", 200, 0.0),
+]
+
+
+def codebook_fit():
+    """Known answers of the reference's codebook TRAINING (sleekit/codebook.py:190-367) on synth.make_samples data."""
+    from sleekit.codebook import lloyd_max
+
+    out = {"cases": np.array(json.dumps(CODEBOOK_FIT_CASES))}
+    for name, count, seed, dtype, size, lam in CODEBOOK_FIT_CASES:
+        data = synth.make_samples(count, seed, np.dtype(dtype).type)
+        start = Codebook.equiprobable(data, size)
+        out[f"{name}/start_values"], out[f"{name}/start_limits"] = start.values, start.thresholds
+        for k in (1, 2, 3):
+            cb = lloyd_max(data, size, lam, max_iter=k)
+            out[f"{name}/round{k}_values"], out[f"{name}/round{k}_limits"] = cb.values, cb.thresholds
+        cb = lloyd_max(data, size, lam)
+        out[f"{name}/final_values"], out[f"{name}/final_limits"] = cb.values, cb.thresholds
+        out[f"{name}/final_shares"] = cb.probabilities(data)
+        out[f"{name}/final_entropy"] = np.float64(cb.entropy(data))
+        out[f"{name}/final_mse"] = np.array(cb.mse(data))
+    # drawn initialisation and subsample: NumPy's global generator, seeded
+    data = synth.make_samples(20000, 34, np.float32)
+    np.random.seed(11)
+    cb = Codebook.random(data, 8)
+    out["random/values"], out["random/limits"] = cb.values, cb.thresholds
+    np.random.seed(12)
+    cb = lloyd_max(data, 8, random_init=True, sample_count=500)
+    out["random_fit/values"], out["random_fit/limits"] = cb.values, cb.thresholds
+    # empty bins: centroids' three fall-backs and remove_unused
+    cb = Codebook([-50.0, -40.0, -0.5, 0.0, 0.25, 0.5, 30.0, 40.0, 50.0])
+    out["empty/centroids"] = cb.centroids(data)
+    cb.remove_unused(data)
+    out["empty/kept_values"], out["empty/kept_limits"] = cb.values, cb.thresholds
+    nf4 = Codebook.nf4()
+    out["nf4/shares"] = nf4.probabilities(data / 4)
+    out["nf4/mse"] = np.array(nf4.mse(data / 4))
+    out["nf4/entropy"] = np.float64(nf4.entropy(data / 4))
+    out["nf4/centroids"] = nf4.centroids(data / 4)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true", help="also (re)generate large_cases.json (minutes)")
     ap.add_argument("--only", nargs="*", help="large shapes to run, e.g. 768x768 (or 4096x4096s1011 for one seed)")
     ap.add_argument("--skip-small", action="store_true", help="leave small_cases.npz and pieces.npz as they are")
     ap.add_argument("--ls-traces", action="store_true", help="(re)generate ls_traces.npz (a minute: runs the large LS cases too)")
+    ap.add_argument("--codebook-fit", action="store_true", help="(re)generate codebook_fit.npz (seconds)")
     args = ap.parse_args()
 
     env = dict(numpy=np.__version__, python=sys.version.split()[0], cpu_count=os.cpu_count())
@@ -396,6 +448,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, "pieces.npz"), **pieces())
         with open(os.path.join(HERE, "environment.json"), "w") as f:
             json.dump(env, f, indent=1)
+    if args.codebook_fit:
+        np.savez_compressed(os.path.join(HERE, "codebook_fit.npz"), **codebook_fit())
     if args.ls_traces:
         np.savez_compressed(os.path.join(HERE, "ls_traces.npz"), **ls_traces())
     if args.large:

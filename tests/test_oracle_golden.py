@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import parse_case
+from oracle import codebook_fit as fit
 from oracle import grid, npsum, obq_ref, scaling_ref, stats_ref
 from sleekit_amd import synth
 
@@ -253,3 +254,46 @@ def test_large_cases_sample(large_cases):
                                              moves=c["moves"], strip=c["strip_mean"]))
     assert sha(idx) == c["sha_idx"]
     assert np.float32(err).tobytes().hex() == c["err_f32_hex"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# codebook training (oracle/codebook_fit.py against the reference's own outputs, bit for bit)
+def test_codebook_fit_matches_the_reference(codebook_fit):
+    import json
+
+    z = codebook_fit
+    for name, count, seed, dtype, size, lam in json.loads(str(z["cases"])):
+        data = synth.make_samples(count, seed, np.dtype(dtype).type)
+        start = fit.equal_mass(data, size)
+        assert np.array_equal(start.values, z[f"{name}/start_values"]) and np.array_equal(start.limits, z[f"{name}/start_limits"])
+        for k in (1, 2, 3):
+            g = fit.fit_lloyd_max(data, size, lam, max_iter=k)
+            assert g.values.dtype == z[f"{name}/round{k}_values"].dtype and g.limits.dtype == z[f"{name}/round{k}_limits"].dtype
+            assert np.array_equal(g.values, z[f"{name}/round{k}_values"]), (name, k)
+            assert np.array_equal(g.limits, z[f"{name}/round{k}_limits"]), (name, k)
+        g = fit.fit_lloyd_max(data, size, lam)
+        assert np.array_equal(g.values, z[f"{name}/final_values"]) and np.array_equal(g.limits, z[f"{name}/final_limits"]), name
+        assert np.array_equal(fit.bin_shares(g, data), z[f"{name}/final_shares"])
+        assert fit.code_entropy(g, data) == z[f"{name}/final_entropy"]
+        mse = fit.mean_square_miss(g, data)
+        assert mse.dtype == z[f"{name}/final_mse"].dtype and mse == z[f"{name}/final_mse"]
+
+
+def test_codebook_fit_drawn_starts_and_empty_bins(codebook_fit):
+    z = codebook_fit
+    data = synth.make_samples(20000, 34, np.float32)
+    np.random.seed(11)
+    g = fit.pick_random(data, 8)
+    assert np.array_equal(g.values, z["random/values"]) and np.array_equal(g.limits, z["random/limits"])
+    np.random.seed(12)
+    g = fit.fit_lloyd_max(data, 8, random_init=True, sample_count=500)
+    assert np.array_equal(g.values, z["random_fit/values"]) and np.array_equal(g.limits, z["random_fit/limits"])
+    g = grid.TableGrid([-50.0, -40.0, -0.5, 0.0, 0.25, 0.5, 30.0, 40.0, 50.0])
+    assert np.array_equal(fit.bin_centres(g, data), z["empty/centroids"])
+    fit.drop_empty_bins(g, data)
+    assert np.array_equal(g.values, z["empty/kept_values"]) and np.array_equal(g.limits, z["empty/kept_limits"])
+    nf4 = grid.TableGrid.nf4()
+    assert np.array_equal(fit.bin_shares(nf4, data / 4), z["nf4/shares"])
+    assert fit.mean_square_miss(nf4, data / 4) == z["nf4/mse"]
+    assert fit.code_entropy(nf4, data / 4) == z["nf4/entropy"]
+    assert np.array_equal(fit.bin_centres(nf4, data / 4), z["nf4/centroids"])

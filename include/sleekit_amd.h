@@ -85,7 +85,8 @@ size_t slk_workspace_bytes(int R, int n);
 int slk_codebook_apply(const float *x, size_t count, int levels, double lo, double hi, const float *table,
                        int what, void *out, slk_stream_t stream);
 
-/* Codebook TRAINING (Lloyd-Max; §8f row 4's other half): what one round of Codebook.improve / centroids /
+/* Codebook TRAINING (Lloyd-Max).  OUTSIDE the hot path of SURVEY.md section 8 (section 2 row 3 marks it out of scope): the
+ * rest of the `sleekit.codebook` surface, built after the path's own work.  What one round of Codebook.improve / centroids /
  * probabilities / mse reads off the data  (sleekit/codebook.py:190-267), in one pass:
  *     counts[k] = #{i : index(x[i]) == k}                      (np.bincount of quantize_index)
  *     sums[k]   = sum of those x[i], float64                   (-> centroid = sums / counts)

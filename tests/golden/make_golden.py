@@ -259,7 +259,7 @@ def pieces():
     # the same two searches step by step (the reference's own functions in its own order, scaling.py:98-134, 160-190),
     # keeping every grid point's row errors: what lets a test PROVE that a row whose chosen factor differs sits on a
     # near-tie of the reference's own errors (they come out of a BLAS product, whose summation order is not ours)
-    for mode, gs in (("hessian", 20), ("obq", 10)):
+    for mode, gs in (("hessian", 20), ("hessian1", 20), ("obq", 10)):
         base = ref_scaling.compute_non_saturating_scaling(L["W"], cb, 0)
         factors = np.linspace(0.05, 1.0, gs, dtype=np.float32)
         errs = []
@@ -275,7 +275,10 @@ def pieces():
                 ref_obq._quantize_opt_block(Q, np.zeros_like(Wp), Hinv, cb, min_block_size=32, num_blocks=8)
                 errs.append(ref_scaling._compute_mse(Hp, ref_scaling.apply_scaling(Q, 1 / sc, 0) - Wp))
             else:
-                errs.append(ref_scaling._compute_mse(L["H"], ref_scaling.quantize_with_scaling(L["W"], sc, cb) - L["W"]))
+                Hm = L["H"]
+                if mode == "hessian1":  # scaling.py:219-222: the damped matrix is float64 (np.eye)
+                    Hm = L["H"] + 0.01 * 1.0 * L["H"].diagonal().mean() * np.eye(L["H"].shape[0])
+                errs.append(ref_scaling._compute_mse(Hm, ref_scaling.quantize_with_scaling(L["W"], sc, cb) - L["W"]))
         errs = np.stack(errs)
         pick = factors[np.argmin(errs, axis=0)]  # first minimum, like the reference's strict `<`
         assert np.array_equal(base * pick, P[f"scale/search_{mode}"]), mode

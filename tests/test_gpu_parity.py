@@ -159,7 +159,7 @@ def test_scale_selection(amd, pieces):
     # full Hessian / OBQ-aware: the row errors come out of a GEMM (the BLAS's summation order there, ours here), so a row
     # may take another grid point ONLY where the reference's own errors of the two points agree to within that rounding:
     # every differing row is checked against the reference's recorded per-point errors (pieces: scale/search_*_errors)
-    for mode, gs in (("hessian", 20), ("obq", 10)):
+    for mode, gs in (("hessian", 20), ("hessian1", 20), ("obq", 10)):
         got = sc.compute_scaling(L["W"], cb, L["H"], mode=mode, grid_size=gs)
         want = pieces[f"scale/search_{mode}"]
         errs, factors, base = (pieces[f"scale/search_{mode}_{k}"] for k in ("errors", "factors", "base"))
@@ -170,8 +170,6 @@ def test_scale_selection(amd, pieces):
             e_dev, e_ref = float(errs[picked[0], r]), float(errs[:, r].min())
             assert e_dev - e_ref <= 4e-6 * e_ref, (mode, int(r), e_dev, e_ref)  # a few float32 roundings of a sum of n^2 terms
         print(mode, "rows on another grid point:", len(rows), "of", len(want))
-    got = sc.compute_scaling(L["W"], cb, L["H"], mode="hessian1", grid_size=20)
-    assert (got == pieces["scale/search_hessian1"]).mean() >= 0.95
     with pytest.raises(RuntimeError):
         sc.compute_scaling(L["W"], cb, L["H"], mode="bogus")
     with pytest.raises(RuntimeError):

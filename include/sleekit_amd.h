@@ -72,7 +72,8 @@ const char *slk_last_error(void);
  * measurement: "no_window2", "no_fast_leaf", "no_defer", "win_dbg", "no_regular_search", "no_fast_search_div",
  * "no_error_splitk", "error_cb", "no_sym_error", "no_bf16_error", "no_bf16_dma", "no_bf16_hessian", "no_bf16_asym",
  * "error_f32_below", "no_wave_search", "lookahead" (a factorisation forks the bulk of its outer updates onto a helper stream: for one layer
- * at a time; sleekit_amd.engine.quantize_layer sets it around its own factorisation) (case-insensitive,
+ * at a time; sleekit_amd.engine.quantize_layer sets it around its own factorisation), "window_rows" (16 or 32 rows per
+ * window workgroup; 0 = 16) (case-insensitive,
  * an "SLK_" prefix is accepted).  Initial values are read ONCE from the environment (SLK_NO_WINDOW2=1 ...);
  * afterwards only these calls change them.  Process-wide, thread-safe; no reference counterpart.              */
 int slk_set_option(const char *name, int value);

@@ -778,11 +778,21 @@ __global__ void k_probe_leaf(double *out, int iters, int mode, Grid g, float inv
     double vacc = 1.0;
     // modes 1-3: leaf waves 0-3, companions 4-7 (same SIMDs if waves go round the SIMDs);
     // mode 4: leaf waves 0, 1, 4, 5 and MFMA companions 2, 3, 6, 7 (other SIMDs under that mapping)
-    const bool leafer = mode == 4 ? (wave & 2) == 0 : wave < 4;
+    const bool leafer = mode == 4 ? (wave & 2) == 0 : (wave < 4 || mode == 0);
     if (mode == 4) mode = leafer ? 0 : 1;
     if (t == 0) out[2] = (double)__builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 4);  // HW_ID, 32 bits... low 16 here
     if (leafer || mode == 0) {
-        for (int it = 0; it < iters; ++it) leaf_registers<32>(sm, sm.lt[0], (wave & 1) + ((wave >> 2) << 1), lane, (it & 1) * 32, 32, g, inv_step);
+        // (with more than two leaf waves per SIMD several waves run the same four rows: garbage values, honest timing)
+        for (int it = 0; it < iters; ++it) leaf_registers<32>(sm, sm.lt[0], ((wave & 1) + ((wave >> 2) << 1)) & 3, lane, (it & 1) * 32, 32, g, inv_step);
+    } else if (mode == 5) {
+        // companion wave on the same SIMD: back-to-back bfloat16 MFMAs (what the layer-error kernel issues)
+        typedef __bf16 probe_bf16x8_t __attribute__((ext_vector_type(8)));
+        typedef float probe_f32x16_t __attribute__((ext_vector_type(16)));
+        probe_bf16x8_t av, bv;
+        for (int k = 0; k < 8; ++k) av[k] = (__bf16)(1.0f + lane), bv[k] = (__bf16)2.0f;
+        probe_f32x16_t c16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int it = 0; it < iters * 64; ++it) c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c16, 0, 0, 0);
+        vacc = c16[0];
     } else if (mode == 1) {
         // companion wave on the same SIMD: back-to-back 16x16x4 MFMAs for about as long
         for (int it = 0; it < iters * 64; ++it) macc = __builtin_amdgcn_mfma_f64_16x16x4f64(1.0 + lane, 2.0, macc, 0, 0, 0);
@@ -794,20 +804,26 @@ __global__ void k_probe_leaf(double *out, int iters, int mode, Grid g, float inv
         for (int it = 0; it < iters * 100; ++it) vacc += sm.lt[1].u[(it + lane) & 31][lane & 31];
     }
     const long long t1 = (long long)__builtin_readcyclecounter();
+    __shared__ long long leaf_cycles[16];
+    if (lane == 0) leaf_cycles[wave] = leafer || mode == 0 ? t1 - t0 : 0;
     __syncthreads();
     if (t == 0) {
         out[0] = (double)(t1 - t0);
         out[1] = sm.q[3][5] + sm.e[2][7];
+        long long slowest = 0;  // the oldest wave of a SIMD issues first: wave 0 alone says nothing about the others
+        for (int w = 0; w < (int)blockDim.x / 64; ++w) slowest = leaf_cycles[w] > slowest ? leaf_cycles[w] : slowest;
+        out[3] = (double)slowest;
     }
     if (macc[0] + vacc == 1.2345e-30) out[1] = macc[0];
 }
 }  // namespace slk
 
 extern "C" int slk_probe_leaf_chain(double *out, int iters, int waves_per_simd, slk_stream_t stream) {
-    // waves_per_simd: 1, 2 (all leaf waves), or 2 + 10 * mode for companions (1 MFMA, 2 fma chain, 3 LDS reads)
+    // waves_per_simd: 1, 2, 3, 4 (all leaf waves), or 2 + 10 * mode for companions (1 float64 MFMA, 2 fma chain, 3 LDS reads,
+    // 5 bfloat16 MFMA)
     const int mode = waves_per_simd / 10;
     waves_per_simd %= 10;
-    SLK_REQUIRE(out && iters > 0 && (waves_per_simd == 1 || waves_per_simd == 2) && mode >= 0 && mode <= 4, "bad arguments");
+    SLK_REQUIRE(out && iters > 0 && waves_per_simd >= 1 && waves_per_simd <= 4 && mode >= 0 && mode <= 5, "bad arguments");
     hipStream_t s = as_stream(stream);
     const Grid g = make_grid(8, -1.0, 1.0);
     SLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_probe_leaf), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -879,7 +895,13 @@ extern "C" int slk_gptq_quantize_batch(const float *W, const float *scale, const
 #endif
     const bool no_defer = opt(OPT_NO_DEFER) != 0;
     SLK_LDS_OPT_IN(k_gptq_window<true>, sizeof(WindowSmem));
-    SLK_LDS_OPT_IN(k_gptq_window2, sizeof(Window2Smem));
+    SLK_LDS_OPT_IN(k_gptq_window2<1>, sizeof(Window2SmemT<1>));
+    SLK_LDS_OPT_IN(k_gptq_window2<2>, sizeof(Window2SmemT<2>));
+    // 32 rows per workgroup halve the CUs a window launch occupies but it lasts 1.55 times as long (114 against 73 us:
+    // two interleaved chains per wave issue twice the instructions, and a chain is issue-bound); in the pipelined bench
+    // the CUs it frees for the other streams and the longer loop chain cancel (4990 against 4980 Mweights/s), so 16 rows
+    // stay the default and 32 a switch (slk_set_option "window_rows")
+    const int window_rows = opt(OPT_WINDOW_ROWS) == 16 || opt(OPT_WINDOW_ROWS) == 32 ? opt(OPT_WINDOW_ROWS) : 16;
     const bool periods_ok = n % 2 == 0 && (uintptr_t)U % 16 == 0 && !opt(OPT_NO_WINDOW2) && (dbg & ~24) == 0;
 
     // rows staged through LDS when they fit and 16-byte accesses line up
@@ -937,10 +959,16 @@ extern "C" int slk_gptq_quantize_batch(const float *W, const float *scale, const
                 }
                 const double wbytes = 12.0 * R * (st.b - st.a) + ub;  // Q in/out + E out, U once
                 PeriodTable pt;
-                if (in_lds && periods_ok && st.ops.size() <= (size_t)MAX_OPS && as_periods(st.ops, st.a, st.b, pt))
-                    SLK_RUN("gptq_window", fl * R, wbytes, s,
-                            k_gptq_window2<<<row_tiles, 512, sizeof(Window2Smem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g, inv_step,
-                                                                                      fast_ok, dbg & 24, pt, rpl));
+                if (in_lds && periods_ok && st.ops.size() <= (size_t)MAX_OPS && as_periods(st.ops, st.a, st.b, pt)) {
+                    if (window_rows == 32)
+                        SLK_RUN_W("gptq_window", fl * R, wbytes, (R + 2 * RB - 1) / (2 * RB), s,
+                                  k_gptq_window2<2><<<(R + 2 * RB - 1) / (2 * RB), 512, sizeof(Window2SmemT<2>), s>>>(
+                                      Qp, Eg, U, R, n, st.a, st.b, g, inv_step, fast_ok, dbg & 24, pt, rpl));
+                    else
+                        SLK_RUN_W("gptq_window", fl * R, wbytes, row_tiles, s,
+                                  k_gptq_window2<1><<<row_tiles, 512, sizeof(Window2SmemT<1>), s>>>(Qp, Eg, U, R, n, st.a, st.b, g, inv_step,
+                                                                                                 fast_ok, dbg & 24, pt, rpl));
+                }
                 else if (in_lds)
                     SLK_RUN("gptq_window", fl * R, wbytes, s,
                             k_gptq_window<true><<<row_tiles, 512, sizeof(WindowSmem), s>>>(Qp, Eg, U, R, n, st.a, st.b, g,

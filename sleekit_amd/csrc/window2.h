@@ -30,21 +30,40 @@ struct PeriodTable {
     Period p[MAXP];
 };
 
-struct Window2Smem {
-    LeafTables lt[2][2];     // [period parity][leaf]
-    double sblk[2][16 * 64]; // U block of the update between the two leaves, in chunks of 4 k x 16 columns
-    double nblk[2][64 * 64]; // U block of the update into the next period, same chunking
-    float q[RB][WPITCH];
-    float e[RB][ERING + 4];
+// SETS = 1: 16 rows per workgroup, every staging buffer double (158 KB).  SETS = 2: 32 rows per workgroup -- a chain
+// wave runs TWO sets of four rows interleaved (the chain is latency-bound: tools/micro_leaf.py measures 126 cycles a
+// column for one, two, three or four chains per SIMD alike), a helper wave folds both 16-row tiles in behind one read
+// of U -- so that a launch of R rows occupies R / 32 CUs for about the same time instead of R / 16: the chip time of
+// the window kernel per row drops by a third and the CUs it leaves go to the other streams' kernels.  The two U
+// blocks are single buffers then (158 KB again), guarded by two LDS counters instead of the buffer parity.
+template <int SETS>
+struct Window2SmemT {
+    LeafTables lt[2][2];                       // [period parity][leaf]
+    double sblk[SETS == 1 ? 2 : 1][16 * 64];   // U block of the update between the two leaves, in chunks of 4 k x 16 columns
+    double nblk[SETS == 1 ? 2 : 1][64 * 64];   // U block of the update into the next period, same chunking
+    float q[RB * SETS][WPITCH];
+    float e[RB * SETS][ERING + 4];
     int odd[2][2][4];        // [parity][leaf][helper wave]: a diagonal defeats the exact-division shortcut
+    int n_done;              // SETS == 2: chain waves through with nblk, 4 per period
+    int s_count;             // SETS == 2: helper waves that have stored their part of sblk, 4 per period from period 1 on
     float cbt[512];          // a general codebook's values and limits (<= 256 entries)
 };
+using Window2Smem = Window2SmemT<1>;
+
+// spin on an LDS counter another wave of the workgroup bumps (acquire: what that wave wrote before is visible after)
+__device__ __forceinline__ void lds_wait_ge(int *counter, int target) {
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void lds_signal(int *counter, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's LDS reads / writes are done
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // The leaf chain on registers (see leaf_registers).  FAST: Markstein divisions (exact unless a
 // significand is all ones, which the caller has excluded); otherwise true divides.
-template <int NSTEP, bool FAST>
-__device__ __forceinline__ void leaf_chain(const LeafTables &lt, int c16, float &x0, float &x1, float &q0, float &q1,
-                                           float &e0, float &e1, const Grid g, float inv_step) {
+template <int NSTEP, bool FAST, int SETS>
+__device__ __forceinline__ void leaf_chain(const LeafTables &lt, int c16, float (&x0)[SETS], float (&x1)[SETS], float (&q0)[SETS],
+                                           float (&q1)[SETS], float (&e0)[SETS], float (&e1)[SETS], const Grid g, float inv_step) {
     double u0n = lt.u[0][c16], u1n = lt.u[0][c16 + 16], uiin = lt.udr[0][0], riin = lt.udr[0][1];
     static_for<0, NSTEP>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -55,40 +74,47 @@ __device__ __forceinline__ void leaf_chain(const LeafTables &lt, int c16, float 
             uiin = lt.udr[i + 1][0];
             riin = lt.udr[i + 1][1];
         }
-        asm volatile("" : "+v"(x0), "+v"(x1)::"memory");  // the reads above are issued before step i starts
+        // the reads above are issued before step i starts
+        if constexpr (SETS == 1) asm volatile("" : "+v"(x0[0]), "+v"(x1[0])::"memory");
+        else asm volatile("" : "+v"(x0[0]), "+v"(x1[0]), "+v"(x0[1]), "+v"(x1[1])::"memory");
         constexpr int src = i & 15;
-        const float xi = row_bcast<src>(i < 16 ? x0 : x1);
-        float q;
-        double err;
-        if (FAST) {
-            q = grid_value_fast(xi, g, inv_step);
-            const double d = (double)(xi - q);
-            const double qq = d * rii;
-            const double rem = __builtin_fma(-uii, qq, d);
-            err = __builtin_fma(rem, rii, qq);
-        } else {
-            q = cb_value(xi, g);
-            err = (double)(xi - q) / uii;
-        }
-        const float ef = (float)err;
         const bool here = c16 == src;
-        if (i < 16) {
-            q0 = here ? q : q0;
-            e0 = here ? ef : e0;
-        } else {
-            q1 = here ? q : q1;
-            e1 = here ? ef : e1;
+#pragma unroll
+        for (int st = 0; st < SETS; ++st) {  // independent chains: the compiler interleaves them
+            const float xi = row_bcast<src>(i < 16 ? x0[st] : x1[st]);
+            float q;
+            double err;
+            if (FAST) {
+                q = grid_value_fast(xi, g, inv_step);
+                const double d = (double)(xi - q);
+                const double qq = d * rii;
+                const double rem = __builtin_fma(-uii, qq, d);
+                err = __builtin_fma(rem, rii, qq);
+            } else {
+                q = cb_value(xi, g);
+                err = (double)(xi - q) / uii;
+            }
+            const float ef = (float)err;
+            if (i < 16) {
+                q0[st] = here ? q : q0[st];
+                e0[st] = here ? ef : e0[st];
+            } else {
+                q1[st] = here ? q : q1[st];
+                e1[st] = here ? ef : e1[st];
+            }
+            if (i < 15) x0[st] = (float)((double)x0[st] - err * u0);
+            if (NSTEP > 16) x1[st] = (float)((double)x1[st] - err * u1);
         }
-        if (i < 15) x0 = (float)((double)x0 - err * u0);
-        if (NSTEP > 16) x1 = (float)((double)x1 - err * u1);
     });
 }
 
+template <int SETS>
 __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, float *__restrict__ Eg,
                                                       const double *__restrict__ U, int R, int n, int w0, int w1,
                                                       Grid g, float inv_step, int fast_ok, int prof, PeriodTable tab, int rpl) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    Window2Smem &sm = *reinterpret_cast<Window2Smem *>(smem_raw);
+    Window2SmemT<SETS> &sm = *reinterpret_cast<Window2SmemT<SETS> *>(smem_raw);
+    constexpr int RBX = RB * SETS;  // rows of this workgroup
     // readfirstlane: tells the compiler the wave index is wave-uniform (scalar branches, SGPR addressing)
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     // cycle accounting (debug, SLK_WIN_DBG bit 3): wave-uniform, workgroup 0, waves 0 and 4
@@ -104,14 +130,22 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
             tmark = now;
         }
     };
-    // Waves go round the four SIMDs (wave i on SIMD i % 4), and the float64 MFMA runs on the same units
-    // as float64 vector arithmetic: a wave issuing MFMAs doubles the time of a leaf chain on ITS SIMD
-    // (tools/micro_leaf.py: 125 -> 254 cycles a column), while two chains share a SIMD at no cost
-    // (latency-bound).  So the chain waves are 0, 1, 4, 5 (SIMDs 0-1), the helpers 2, 3, 6, 7 (SIMDs 2-3).
-    const bool helper = (wave & 2) != 0;
-    const int role_wave = (wave & 1) + ((wave >> 2) << 1);  // 0-3 within the role
+    // Waves go round the four SIMDs (wave i on SIMD i % 4).  A leaf chain is bound by the ISSUE of its own instructions,
+    // not by their latency: two chains on one SIMD take turns, oldest first -- tools/micro_leaf.py: 127 cycles a column
+    // for one chain wave per SIMD, 189 for the slower of two, 348 of four (round 1 timed wave 0 only, the oldest, and
+    // concluded the opposite) -- and a wave issuing float64 MFMAs back to back doubles the chain on its SIMD (255).  The
+    // helpers issue MFMAs a fraction of their time, so one chain wave AND one helper wave per SIMD (chain waves 0-3,
+    // helpers 4-7) beats two chains on SIMDs 0-1 and the helpers on 2-3: 80.5 -> 73.3 us per launch, 4880 -> 4980
+    // Mweights/s.
+    const bool helper = wave >= 4;
+    const int role_wave = wave & 3;  // 0-3 within the role
+    constexpr int first_helper = 4;
+    // The oldest wave of a SIMD issues first, so a helper (waves 4-7) would only get the slots its chain wave leaves; in
+    // the first periods the helpers are the longer side, and with raised priority the two meet in the middle (73.0 ->
+    // 70.0 us per launch; the same priority on the chain waves instead changes nothing, they are the oldest already).
+    if (helper) __builtin_amdgcn_s_setprio(3);
     const int ht = role_wave * 64 + lane;                   // thread index within the role, 0-255
-    const int r0 = blockIdx.x * RB;
+    const int r0 = blockIdx.x * RBX;
     U += (size_t)(r0 / rpl) * n * n;  // a batch of layers stacked by rows: rows [b rpl, (b + 1) rpl) use factor b
     const int np = tab.count;
     const int width = w1 - w0;
@@ -128,7 +162,7 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
     auto load_cols = [&](int c_lo, int c_hi, int tid, int nth) {
         const int cw = c_hi - c_lo;
         if (vec4 && (c_lo & 3) == 0 && (cw & 3) == 0) {
-            const int cw4 = cw >> 2, total = RB * cw4;
+            const int cw4 = cw >> 2, total = RBX * cw4;
             for (int e0 = tid; e0 < total; e0 += 4 * nth) {
                 float4v_t v[4];
 #pragma unroll
@@ -146,7 +180,7 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
             }
             return;
         }
-        const int total = RB * cw;
+        const int total = RBX * cw;
         for (int e0 = tid; e0 < total; e0 += 8 * nth) {
             float v[8];
 #pragma unroll
@@ -165,27 +199,42 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
     };
     const Period P0 = tab.p[0];
     const int end0 = P0.s + P0.w1 + P0.w2;
+    if (SETS == 2 && t == 0) sm.n_done = 0, sm.s_count = 0;  // visible after B_start
 
     if (!helper) {
         // ======================================================== chain waves
-        const int c16 = lane & 15, rg = lane >> 4, row = 4 * role_wave + rg;
-        const bool row_live = r0 + row < R;
+        const int c16 = lane & 15, rg = lane >> 4;
+        int row[SETS];
+        bool row_live[SETS];
+#pragma unroll
+        for (int st = 0; st < SETS; ++st) row[st] = RB * st + 4 * role_wave + rg, row_live[st] = r0 + row[st] < R;
         // Q[rows, dst0 : dst0 + N] -= E[rows, src0 : src0 + K] @ (U block in `chunks`), this wave's four rows.
         // A operand: lane 16 k + 4 q + i carries E[i][k] (the same for the four column quads q);
         // B operand: lane 16 k + c carries U[k][c]: chunk (cg, ks) is read as 512 contiguous bytes.
         auto local_update = [&](const double *chunks, int src0, int K, int dst0, int N) {
             const int ncg = (N + 15) >> 4, nks = (K + 3) >> 2;
             const int ai = lane & 3, ak = lane >> 4;
-            const float *erow = &sm.e[4 * role_wave + ai][0];
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            const float *erow[SETS];
+            double acc[SETS][4];
+#pragma unroll
+            for (int st = 0; st < SETS; ++st) {
+                erow[st] = &sm.e[RB * st + 4 * role_wave + ai][0];
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) acc[st][cg] = 0.0;
+            }
             auto body = [&](auto nks_c, auto ncg_c) {
                 constexpr int NKS = decltype(nks_c)::value, NCG = decltype(ncg_c)::value;
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    const double a = (double)erow[ring(src0 + 4 * ks + ak)];
+                    double a[SETS];
 #pragma unroll
-                    for (int cg = 0; cg < NCG; ++cg)
-                        acc[cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, chunks[(size_t)(cg * NKS + ks) * 64 + lane], acc[cg], 0, 0, 0);
+                    for (int st = 0; st < SETS; ++st) a[st] = (double)erow[st][ring(src0 + 4 * ks + ak)];
+#pragma unroll
+                    for (int cg = 0; cg < NCG; ++cg) {
+                        const double bchunk = chunks[(size_t)(cg * NKS + ks) * 64 + lane];
+#pragma unroll
+                        for (int st = 0; st < SETS; ++st) acc[st][cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[st], bchunk, acc[st][cg], 0, 0, 0);
+                    }
                 }
             };
             using std::integral_constant;
@@ -194,19 +243,28 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
             else {
                 for (int ks = 0; ks < nks; ++ks) {
                     const int kk = src0 + 4 * ks + ak;
-                    const float ev = erow[ring(min(kk, src0 + K - 1))];
-                    const double a = kk < src0 + K ? (double)ev : 0.0;
+                    double a[SETS];
+#pragma unroll
+                    for (int st = 0; st < SETS; ++st) {
+                        const float ev = erow[st][ring(min(kk, src0 + K - 1))];
+                        a[st] = kk < src0 + K ? (double)ev : 0.0;
+                    }
 #pragma unroll
                     for (int cg = 0; cg < 4; ++cg)
-                        if (cg < ncg)
-                            acc[cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, chunks[(size_t)(cg * nks + ks) * 64 + lane], acc[cg], 0, 0, 0);
+                        if (cg < ncg) {
+                            const double bchunk = chunks[(size_t)(cg * nks + ks) * 64 + lane];
+#pragma unroll
+                            for (int st = 0; st < SETS; ++st) acc[st][cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[st], bchunk, acc[st][cg], 0, 0, 0);
+                        }
                 }
             }
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) {
-                const int col = dst0 + 16 * cg + c16;
-                if (cg < ncg && col < dst0 + N) sm.q[row][col - w0] = (float)((double)sm.q[row][col - w0] - acc[cg]);
-            }
+            for (int st = 0; st < SETS; ++st)
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) {
+                    const int col = dst0 + 16 * cg + c16;
+                    if (cg < ncg && col < dst0 + N) sm.q[row[st]][col - w0] = (float)((double)sm.q[row[st]][col - w0] - acc[st][cg]);
+                }
         };
 
         load_cols(w0, end0, t, 512);  // with the helpers' half
@@ -220,25 +278,36 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                 const int w = lf ? P.w2 : P.w1;
                 if (w == 0) break;
                 const int a = lf ? P.s + P.w1 : P.s;
-                if (lf) local_update(sm.sblk[par], P.s, P.w1, a, w);
+                if (lf) {
+                    if (SETS == 2) lds_wait_ge(&sm.s_count, 4 * p);  // the helpers store period p's block at the top of interval p
+                    local_update(sm.sblk[SETS == 1 ? par : 0], P.s, P.w1, a, w);
+                }
                 lap(2);
                 const LeafTables &lt = sm.lt[par][lf];
                 const bool fast = fast_ok && (sm.odd[par][lf][0] | sm.odd[par][lf][1] | sm.odd[par][lf][2] | sm.odd[par][lf][3]) == 0;
                 const bool m0 = c16 < w, m1 = c16 + 16 < w;
-                float x0 = m0 ? sm.q[row][a - w0 + c16] : 0.0f, x1 = m1 ? sm.q[row][a - w0 + 16 + c16] : 0.0f;
-                float q0 = 0.0f, q1 = 0.0f, e0 = 0.0f, e1 = 0.0f;
-                if (!fast) leaf_chain<32, false>(lt, c16, x0, x1, q0, q1, e0, e1, g, inv_step);
-                else if (w <= 16) leaf_chain<16, true>(lt, c16, x0, x1, q0, q1, e0, e1, g, inv_step);
-                else leaf_chain<32, true>(lt, c16, x0, x1, q0, q1, e0, e1, g, inv_step);
-                if (m0) {
-                    sm.q[row][a - w0 + c16] = q0;
-                    sm.e[row][ring(a + c16)] = e0;
-                    if (row_live) Eg[(size_t)(r0 + row) * n + a + c16] = e0;
+                float x0[SETS], x1[SETS], q0[SETS], q1[SETS], e0[SETS], e1[SETS];
+#pragma unroll
+                for (int st = 0; st < SETS; ++st) {
+                    x0[st] = m0 ? sm.q[row[st]][a - w0 + c16] : 0.0f;
+                    x1[st] = m1 ? sm.q[row[st]][a - w0 + 16 + c16] : 0.0f;
+                    q0[st] = q1[st] = e0[st] = e1[st] = 0.0f;
                 }
-                if (m1) {
-                    sm.q[row][a - w0 + 16 + c16] = q1;
-                    sm.e[row][ring(a + 16 + c16)] = e1;
-                    if (row_live) Eg[(size_t)(r0 + row) * n + a + 16 + c16] = e1;
+                if (!fast) leaf_chain<32, false, SETS>(lt, c16, x0, x1, q0, q1, e0, e1, g, inv_step);
+                else if (w <= 16) leaf_chain<16, true, SETS>(lt, c16, x0, x1, q0, q1, e0, e1, g, inv_step);
+                else leaf_chain<32, true, SETS>(lt, c16, x0, x1, q0, q1, e0, e1, g, inv_step);
+#pragma unroll
+                for (int st = 0; st < SETS; ++st) {
+                    if (m0) {
+                        sm.q[row[st]][a - w0 + c16] = q0[st];
+                        sm.e[row[st]][ring(a + c16)] = e0[st];
+                        if (row_live[st]) Eg[(size_t)(r0 + row[st]) * n + a + c16] = e0[st];
+                    }
+                    if (m1) {
+                        sm.q[row[st]][a - w0 + 16 + c16] = q1[st];
+                        sm.e[row[st]][ring(a + 16 + c16)] = e1[st];
+                        if (row_live[st]) Eg[(size_t)(r0 + row[st]) * n + a + 16 + c16] = e1[st];
+                    }
                 }
                 lap(1);
             }
@@ -246,7 +315,8 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
             __syncthreads();  // B_p
             tper = timing ? (long long)__builtin_readcyclecounter() : 0;
             lap(3);
-            if (P.nw) local_update(sm.nblk[par], P.s, P.w1 + P.w2, P.s + P.w1 + P.w2, P.nw);
+            if (P.nw) local_update(sm.nblk[SETS == 1 ? par : 0], P.s, P.w1 + P.w2, P.s + P.w1 + P.w2, P.nw);
+            if (SETS == 2) lds_signal(&sm.n_done, lane);  // nblk may be overwritten (every period, to keep the count simple)
             lap(2);
         }
     } else {
@@ -350,41 +420,51 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                 bv[s4] = U[(size_t)min(k, b - 1) * n + cc];
             }
         };
-        auto mac_round = [&](int a, int b, int kc, const double(&bv)[16], double4_t &acc) {
+        auto mac_round = [&](int a, int b, int kc, const double(&bv)[16], double4_t(&acc)[SETS]) {
             const int kbase = a + 64 * kc, kcount = min(64, b - kbase);
             if ((kcount == 64 || kcount == 32) && ((kbase - w0) & 31) == 0) {
-                const float *ep = &sm.e[lr][ring(kbase) + lk];  // 32-aligned: the chunk does not wrap
-                float av[16];
 #pragma unroll
-                for (int s4 = 0; s4 < 8; ++s4) av[s4] = ep[4 * s4];
-                if (kcount == 64) {
+                for (int st = 0; st < SETS; ++st) {  // the round of U in registers serves every 16-row tile
+                    const float *ep = &sm.e[RB * st + lr][ring(kbase) + lk];  // 32-aligned: the chunk does not wrap
+                    float av[16];
 #pragma unroll
-                    for (int s4 = 8; s4 < 16; ++s4) av[s4] = ep[4 * s4];
-                }
+                    for (int s4 = 0; s4 < 8; ++s4) av[s4] = ep[4 * s4];
+                    if (kcount == 64) {
 #pragma unroll
-                for (int s4 = 0; s4 < 8; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[s4], bv[s4], acc, 0, 0, 0);
-                if (kcount == 64) {
+                        for (int s4 = 8; s4 < 16; ++s4) av[s4] = ep[4 * s4];
+                    }
 #pragma unroll
-                    for (int s4 = 8; s4 < 16; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[s4], bv[s4], acc, 0, 0, 0);
+                    for (int s4 = 0; s4 < 8; ++s4) acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[s4], bv[s4], acc[st], 0, 0, 0);
+                    if (kcount == 64) {
+#pragma unroll
+                        for (int s4 = 8; s4 < 16; ++s4) acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[s4], bv[s4], acc[st], 0, 0, 0);
+                    }
                 }
             } else {
 #pragma unroll
                 for (int s4 = 0; s4 < 16; ++s4) {
                     const int k = kbase + 4 * s4 + lk;
-                    const float ev = sm.e[lr][ring(min(k, b - 1))];
-                    const double av = k < b ? (double)ev : 0.0;
-                    if (4 * s4 < kcount) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[s4], acc, 0, 0, 0);
+#pragma unroll
+                    for (int st = 0; st < SETS; ++st) {
+                        const float ev = sm.e[RB * st + lr][ring(min(k, b - 1))];
+                        const double av = k < b ? (double)ev : 0.0;
+                        if (4 * s4 < kcount) acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[s4], acc[st], 0, 0, 0);
+                    }
                 }
             }
         };
-        auto store_block = [&](int lo, int hi, int blk, const double4_t &acc) {
+        auto store_block = [&](int lo, int hi, int blk, double4_t(&acc)[SETS]) {  // and clear the accumulators
             const int col = lo + blk * 16 + lr;
-            if (col < hi) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rr = lk + 4 * r;
-                    sm.q[rr][col - w0] = (float)((double)sm.q[rr][col - w0] - acc[r]);
+            for (int st = 0; st < SETS; ++st) {
+                if (col < hi) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = RB * st + lk + 4 * r;
+                        sm.q[rr][col - w0] = (float)((double)sm.q[rr][col - w0] - acc[st][r]);
+                    }
                 }
+                acc[st] = (double4_t){0.0, 0.0, 0.0, 0.0};
             }
         };
         // Rounds in pairs on two register buffers.  The loads of the round after next are issued
@@ -398,8 +478,9 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
             const int last_blk = wid + ((nblk - wid - 1) / nw) * nw;
             double other[16];
             load_round(a, b, lo, hi, wid, 0, cur);
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
-            const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+            double4_t acc[SETS];
+#pragma unroll
+            for (int st = 0; st < SETS; ++st) acc[st] = (double4_t){0.0, 0.0, 0.0, 0.0};
             int blk = wid, kc = 0;
             for (int r = 0; r < nr; r += 2) {
                 int blk1 = blk, kc1 = kc + 1;
@@ -407,20 +488,14 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                 const bool has1 = r + 1 < nr;
                 load_round(a, b, lo, hi, has1 ? blk1 : last_blk, has1 ? kc1 : nchunk - 1, other);
                 mac_round(a, b, kc, cur, acc);
-                if (kc + 1 == nchunk) {
-                    store_block(lo, hi, blk, acc);
-                    acc = zero4;
-                }
+                if (kc + 1 == nchunk) store_block(lo, hi, blk, acc);
                 int blk2 = blk1, kc2 = kc1 + 1;
                 if (kc2 == nchunk) kc2 = 0, blk2 += nw;
                 const bool has2 = r + 2 < nr;
                 load_round(a, b, lo, hi, has2 ? blk2 : last_blk, has2 ? kc2 : nchunk - 1, cur);
                 if (has1) {
                     mac_round(a, b, kc1, other, acc);
-                    if (kc1 + 1 == nchunk) {
-                        store_block(lo, hi, blk1, acc);
-                        acc = zero4;
-                    }
+                    if (kc1 + 1 == nchunk) store_block(lo, hi, blk1, acc);
                 }
                 blk = blk2, kc = kc2;
             }
@@ -441,6 +516,12 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
             // interval I_p, while the chain waves run period p
             const Period P = tab.p[p];
             const int K = P.w1 + P.w2;
+            if (SETS == 2 && p >= 1) {
+                // single sblk: period p's block (in registers since the last interval) goes in now, after the barrier
+                // that ended the chain waves' reads of period p - 1's; they wait for all four helper waves' parts
+                if (P.w2) stage_store(steps_s, sreg, sm.sblk[0], P.w1, P.w2);
+                lds_signal(&sm.s_count, lane);
+            }
             // registers first: a wait for the table values (fetched an interval ago) must not have the
             // block loads below in front of it -- vmcnt completes in order
             write_tables(p + 1);
@@ -461,9 +542,10 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                 if (lo < w1) run_update(M.s, M.s + M.w1 + M.w2, lo, w1, role_wave, 4);
             }
             lap(5);
-            if (P.nw) stage_store(steps_n, nreg, sm.nblk[p & 1], K, P.nw);
-            if (has_s) stage_store(steps_s, sreg, sm.sblk[(p + 1) & 1], N1.w1, N1.w2);
-            if (timing && lane == 0 && wave == 2) g_win_trace[32 + p] += (long long)__builtin_readcyclecounter() - tper;
+            if (SETS == 2) lds_wait_ge(&sm.n_done, 4 * p);  // single nblk: the chain waves are through with period p - 1's block
+            if (P.nw) stage_store(steps_n, nreg, sm.nblk[SETS == 1 ? (p & 1) : 0], K, P.nw);
+            if (SETS == 1 && has_s) stage_store(steps_s, sreg, sm.sblk[(p + 1) & 1], N1.w1, N1.w2);
+            if (timing && lane == 0 && wave == first_helper) g_win_trace[32 + p] += (long long)__builtin_readcyclecounter() - tper;
             __syncthreads();  // B_p
             tper = timing ? (long long)__builtin_readcyclecounter() : 0;
             lap(7);
@@ -473,17 +555,17 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
     // every column is final: the tile goes back (E went out leaf by leaf)
     if (vec4 && (width & 3) == 0) {
         const int cw4 = width >> 2;
-        for (int e = t; e < RB * cw4; e += 512) {
+        for (int e = t; e < RBX * cw4; e += 512) {
             const int r = e / cw4, c = 4 * (e % cw4);
             if (r0 + r < R) *reinterpret_cast<float4v_t *>(Qp + (size_t)(r0 + r) * n + w0 + c) = *reinterpret_cast<const float4v_t *>(&sm.q[r][c]);
         }
     } else {
-        for (int e = t; e < RB * width; e += 512) {
+        for (int e = t; e < RBX * width; e += 512) {
             const int r = e / width, c = e % width;
             if (r0 + r < R) Qp[(size_t)(r0 + r) * n + w0 + c] = sm.q[r][c];
         }
     }
-    if (timing && lane == 0 && (wave == 0 || wave == 2)) {
+    if (timing && lane == 0 && (wave == 0 || wave == first_helper)) {
 #pragma unroll
         for (int k = 0; k < 12; ++k)
             if (tacc[k] && k != 9) g_win_cycles[k] += tacc[k];

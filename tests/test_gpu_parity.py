@@ -320,23 +320,26 @@ def test_window_kernels_agree(amd, n, odd_diagonal, slkopt):
     BASELINE width (one- and two-leaf periods, 32 + 16 and 5 x 32 + 12 leaves), a ragged last row
     tile, and a diagonal entry with an all-ones significand (exact-division exception: true divides)."""
     rng = np.random.default_rng(n)
-    R = 40
+    R = 40 if n != 1024 else 109  # ragged last tiles of 16 and of 32 rows
     W = (rng.standard_normal((R, n)) * 0.6).astype(np.float32)
     U = np.triu(rng.standard_normal((n, n)) * (0.3 / np.sqrt(n))) + np.diag(1.0 + rng.random(n))
     if odd_diagonal:
         U[n // 3, n // 3] = np.nextafter(2.0, 0.0)  # 1.111...1b: the fma division shortcut is not exact for it
     cb = amd.codebook.UniformCodebook(8, -1, 1)
     out = []
-    for general in (False, True):
-        if general:
+    for variant in ("rows16", "rows32", "general"):
+        if variant == "general":
             slkopt.setenv("SLK_NO_WINDOW2", "1")
         else:
             slkopt.delenv("SLK_NO_WINDOW2", raising=False)
+            slkopt.setenv("SLK_WINDOW_ROWS", variant[4:])  # 32: two interleaved sets of rows per chain wave, single U buffers
         Q, E = W.copy(), np.zeros_like(W)
         amd.obq._quantize_opt_block(Q, E, U, cb, 32, 8)
         out.append((Q, E))
-    assert np.array_equal(out[0][0], out[1][0])
-    assert np.array_equal(out[0][1], out[1][1])
+    slkopt.delenv("SLK_WINDOW_ROWS")
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0])
+        assert np.array_equal(out[0][1], other[1])
     # and both against the oracle on the narrow cases (seconds on the CPU)
     if n <= 1024:
         Q0, E0 = W.copy(), np.zeros_like(W)

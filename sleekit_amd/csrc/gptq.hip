@@ -180,7 +180,18 @@ __device__ __forceinline__ void static_for(F &&f) {
 // lane L of every 16-lane row, to all lanes of that row (DPP row_newbcast, gfx90a and later)
 template <int L>
 __device__ __forceinline__ float row_bcast(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + L, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + L, 0xf, 0xf, true));
+}
+// grid_value_fast of lane L's x (a broadcast of its own, which folds into the first subtraction), clamp by one v_med3
+template <int L>
+__device__ __forceinline__ float grid_value_fast_dpp(float x, const Grid g, float inv_step) {
+    const float t0 = row_bcast<L>(x) - g.zero;
+    const float q0 = t0 * inv_step;
+    const float r = __builtin_fmaf(-g.step, q0, t0);
+    float t = __builtin_fmaf(r, inv_step, q0);
+    t = rintf(t);
+    t = __builtin_amdgcn_fmed3f(t, 0.0f, g.top);
+    return t * g.step + g.zero;
 }
 
 // LEAF, register path (width <= 32, window in LDS), run by waves 0-3 of the workgroup: a wave
@@ -902,7 +913,7 @@ extern "C" int slk_gptq_quantize_batch(const float *W, const float *scale, const
     // the CUs it frees for the other streams and the longer loop chain cancel (4990 against 4980 Mweights/s), so 16 rows
     // stay the default and 32 a switch (slk_set_option "window_rows")
     const int window_rows = opt(OPT_WINDOW_ROWS) == 16 || opt(OPT_WINDOW_ROWS) == 32 ? opt(OPT_WINDOW_ROWS) : 16;
-    const bool periods_ok = n % 2 == 0 && (uintptr_t)U % 16 == 0 && !opt(OPT_NO_WINDOW2) && (dbg & ~24) == 0;
+    const bool periods_ok = n % 2 == 0 && n <= 16384 && (uintptr_t)U % 16 == 0 && !opt(OPT_NO_WINDOW2) && (dbg & ~24) == 0;
 
     // rows staged through LDS when they fit and 16-byte accesses line up
     const bool perm_lds = order && n % 4 == 0 && n <= PERM_MAX && ((uintptr_t)W | (uintptr_t)Q | (uintptr_t)workspace) % 16 == 0 &&

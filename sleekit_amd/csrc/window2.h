@@ -81,11 +81,15 @@ __device__ __forceinline__ void leaf_chain(const LeafTables &lt, int c16, float 
         const bool here = c16 == src;
 #pragma unroll
         for (int st = 0; st < SETS; ++st) {  // independent chains: the compiler interleaves them
-            const float xi = row_bcast<src>(i < 16 ? x0[st] : x1[st]);
+            // the broadcast value has two consumers (the quantizer's first subtraction and the residual): two DPP moves,
+            // each with a single use, so that the compiler folds each into its consumer (v_sub_f32_dpp) -- the chain is
+            // bound by the issue of its ~28 instructions a column, every one off it counts
+            const float xsrc = i < 16 ? x0[st] : x1[st];
+            const float xi = row_bcast<src>(xsrc);
             float q;
             double err;
             if (FAST) {
-                q = grid_value_fast(xi, g, inv_step);
+                q = grid_value_fast_dpp<src>(xsrc, g, inv_step);
                 const double d = (double)(xi - q);
                 const double qq = d * rii;
                 const double rem = __builtin_fma(-uii, qq, d);
@@ -412,11 +416,27 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
         double cur[16];
         // (Scalar per-row-group bases with one vector offset were tried to take the address arithmetic
         // off the vector ALU, which the float64 MFMA shares: the SALU chain it needs is slower, 36 vs 31 us.)
+        // The helpers share their SIMDs' issue slots with the chain waves, so the address arithmetic counts: a full chunk
+        // of 64 rows (the common case) is read at a uniform base + a 32-bit byte offset that advances by a constant
+        // (one v_add_u32 per load; the clamped form below costs an add, a min, a 64-bit multiply-add and a 64-bit
+        // shift-add each).  n <= 16384 (checked on the host) keeps the offset below 2^32.
+        const char *Ubytes = reinterpret_cast<const char *>(U);
+        const unsigned row4 = 32u * (unsigned)n;  // bytes from row k to row k + 4
         auto load_round = [&](int a, int b, int lo, int hi, int blk, int kc, double(&bv)[16]) {
             const int cc = min(lo + blk * 16 + lr, hi - 1);
+            const int kbase = a + 64 * kc;
+            if (kbase + 64 <= b) {
+                unsigned off = ((unsigned)(kbase + lk) * (unsigned)n + (unsigned)cc) * 8u;
+#pragma unroll
+                for (int s4 = 0; s4 < 16; ++s4) {
+                    bv[s4] = *reinterpret_cast<const double *>(Ubytes + off);
+                    off += row4;
+                }
+                return;
+            }
 #pragma unroll
             for (int s4 = 0; s4 < 16; ++s4) {
-                const int k = a + 64 * kc + 4 * s4 + lk;
+                const int k = kbase + 4 * s4 + lk;
                 bv[s4] = U[(size_t)min(k, b - 1) * n + cc];
             }
         };

@@ -25,6 +25,8 @@ The JSON line also carries
                  workgroups counts for that share of its duration); achieved = ALGORITHMIC flops or bytes of its
                  launches / their summed duration; `alone` = the same kernel in a single-stream pass (no other
                  kernel shares the chip); `single_stream_leader` = the kernel that leads that pass, when another;
+                 `loop` = the whole error-update loop (window + trailing kernels: SURVEY.md 8 a8 + a9) priced as one
+                 thing, alone and as timed;
   latency_ms_single_layer   one isolated layer, start to finish (SURVEY.md 8e);
   asymmetric_H  the same workload with Hessians made by torch `X.T @ X` (not bit-symmetric, like the experiments' dumps):
                  the layer error then cannot halve its work;
@@ -349,6 +351,24 @@ def main():
                 roofline["alone"] = {"avg_launch_us": d["avg_launch_us"], "achieved": d["achieved"], "frac": d["frac"],
                                      "share_of_chip_time": d["share_of_chip_time"],
                                      "note": "single-stream pass after the timed region: no other kernel shares the chip"}
+            # the whole error-update loop (SURVEY.md 8 a8 + a9: leaf chains and every blocked update = window + trailing
+            # kernels; north_star prices the loop as one thing): its algorithmic float64 flops over the summed launch time
+            def loop_rate(tab):
+                ks = [k for k in tab if k["kernel"] in ("gptq_window", "gptq_window_wide", "gptq_trailing")]
+                ms, fl = sum(k["total_ms"] for k in ks), sum(k["flops"] for k in ks)
+                return ms, fl
+            ms_a, fl_a = loop_rate(seq)
+            ms_t, fl_t = loop_rate(table)
+            if ms_a > 0 and ms_t > 0:
+                peak64 = PEAK["mfma_f64"][0]
+                roofline["loop"] = {
+                    "kernels": "gptq_window + gptq_trailing", "bound": "mfma", "peak": peak64 / 1e12, "unit": "TFLOP/s",
+                    "algorithmic_flops_per_layer": fl_a / L,
+                    "alone": {"ms_per_layer": round(ms_a / L, 4), "achieved": round(fl_a / ms_a / 1e9, 3), "frac": round(fl_a / ms_a / 1e9 / (peak64 / 1e12), 4)},
+                    "timed": {"ms_per_layer": round(ms_t / args.steps / L, 4), "achieved": round(fl_t / ms_t / 1e9, 3),
+                              "frac": round(fl_t / ms_t / 1e9 / (peak64 / 1e12), 4),
+                              "note": "launch durations while other layers' kernels share the CUs"},
+                }
             lead = max(seq, key=lambda k: k["chip_ms"])
             if lead["kernel"] != roofline["kernel"]:
                 d = describe(lead, seq)

@@ -182,10 +182,9 @@ template <int L>
 __device__ __forceinline__ float row_bcast(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + L, 0xf, 0xf, true));
 }
-// grid_value_fast of lane L's x (a broadcast of its own, which folds into the first subtraction), clamp by one v_med3
-template <int L>
-__device__ __forceinline__ float grid_value_fast_dpp(float x, const Grid g, float inv_step) {
-    const float t0 = row_bcast<L>(x) - g.zero;
+// grid_value_fast with the clamp as one v_med3 (the leaf chain counts instructions)
+__device__ __forceinline__ float grid_value_fast_med3(float x, const Grid g, float inv_step) {
+    const float t0 = x - g.zero;
     const float q0 = t0 * inv_step;
     const float r = __builtin_fmaf(-g.step, q0, t0);
     float t = __builtin_fmaf(r, inv_step, q0);

@@ -78,38 +78,54 @@ __device__ __forceinline__ void leaf_chain(const LeafTables &lt, int c16, float 
         if constexpr (SETS == 1) asm volatile("" : "+v"(x0[0]), "+v"(x1[0])::"memory");
         else asm volatile("" : "+v"(x0[0]), "+v"(x1[0]), "+v"(x0[1]), "+v"(x1[1])::"memory");
         constexpr int src = i & 15;
-        const bool here = c16 == src;
 #pragma unroll
         for (int st = 0; st < SETS; ++st) {  // independent chains: the compiler interleaves them
-            // the broadcast value has two consumers (the quantizer's first subtraction and the residual): two DPP moves,
-            // each with a single use, so that the compiler folds each into its consumer (v_sub_f32_dpp) -- the chain is
-            // bound by the issue of its ~28 instructions a column, every one off it counts
-            const float xsrc = i < 16 ? x0[st] : x1[st];
-            const float xi = row_bcast<src>(xsrc);
-            float q;
+            // column i of each of the wave's rows, broadcast inside its 16-lane DPP row; every lane recomputes the
+            // column's error for its own row.  The chain is bound by the ISSUE of these instructions: nothing is kept
+            // per step (the column's own q and e come after the loop, below)
+            const float xi = row_bcast<src>(i < 16 ? x0[st] : x1[st]);
             double err;
             if (FAST) {
-                q = grid_value_fast_dpp<src>(xsrc, g, inv_step);
+                const float q = grid_value_fast_med3(xi, g, inv_step);
                 const double d = (double)(xi - q);
                 const double qq = d * rii;
                 const double rem = __builtin_fma(-uii, qq, d);
                 err = __builtin_fma(rem, rii, qq);
             } else {
-                q = cb_value(xi, g);
-                err = (double)(xi - q) / uii;
-            }
-            const float ef = (float)err;
-            if (i < 16) {
-                q0[st] = here ? q : q0[st];
-                e0[st] = here ? ef : e0[st];
-            } else {
-                q1[st] = here ? q : q1[st];
-                e1[st] = here ? ef : e1[st];
+                err = (double)(xi - cb_value(xi, g)) / uii;
             }
             if (i < 15) x0[st] = (float)((double)x0[st] - err * u0);
             if (NSTEP > 16) x1[st] = (float)((double)x1[st] - err * u1);
         }
     });
+    // A lane's own columns are final once their step has passed: the block of U is zero on and below the diagonal, so
+    // the later steps subtract err * 0 (at most the sign of a zero changes, which no result can see).  Their q and e
+    // are the same expressions on the same value as in the step that broadcast it: computed once here instead of being
+    // selected into place in every step (two v_cndmask and a conversion per step less on the chain).
+    const double d0 = lt.udr[c16][0], r0 = lt.udr[c16][1];
+    const double d1 = lt.udr[NSTEP > 16 ? c16 + 16 : c16][0], r1 = lt.udr[NSTEP > 16 ? c16 + 16 : c16][1];
+#pragma unroll
+    for (int st = 0; st < SETS; ++st) {
+#pragma unroll
+        for (int half = 0; half < (NSTEP > 16 ? 2 : 1); ++half) {
+            const float xv = half ? x1[st] : x0[st];
+            const double uii = half ? d1 : d0, rii = half ? r1 : r0;
+            float q;
+            double err;
+            if (FAST) {
+                q = grid_value_fast_med3(xv, g, inv_step);
+                const double d = (double)(xv - q);
+                const double qq = d * rii;
+                const double rem = __builtin_fma(-uii, qq, d);
+                err = __builtin_fma(rem, rii, qq);
+            } else {
+                q = cb_value(xv, g);
+                err = (double)(xv - q) / uii;
+            }
+            if (half) q1[st] = q, e1[st] = (float)err;
+            else q0[st] = q, e0[st] = (float)err;
+        }
+    }
 }
 
 template <int SETS>

@@ -78,7 +78,7 @@ enum Opt {
     OPT_NO_BF16_ERROR,         // layer error: float32 MFMA kernel
     OPT_NO_BF16_DMA,           // bfloat16 x 3 GEMMs: stage operands through registers
     OPT_NO_BF16_HESSIAN,       // Hessian accumulation: float32 MFMA kernel
-    OPT_ERROR_F32_BELOW,       // layer error of a batch: float32 kernel when a layer has fewer rows than this (0: 1024, < 0: never)
+    OPT_ERROR_F32_BELOW,       // layer error of a batch: float32 kernel when a layer has fewer rows than this (0: never, the default)
     OPT_NO_BF16_ASYM,          // layer error: an H that is not symmetric goes to the float32 kernel
     OPT_NO_WAVE_SEARCH,        // local search: the workgroup-per-row kernel for every row length
     OPT_LOOKAHEAD,             // factorisation: the bulk of an outer syrk on a helper stream, beside the next block's panels

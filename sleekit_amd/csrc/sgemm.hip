@@ -602,10 +602,12 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
             SLK_RUN("symmetry_check", 0, 4.0 * n * n, s, k_symmetry_flag<<<t64 * (t64 + 1) / 2, 256, 0, s>>>(Hs[b], n, sym + b));
     }
     // the bfloat16 x 3 kernel when the shape allows (16-byte loads, whole tiles of columns).  Its operands are split into
-    // planes first, 10 bytes of traffic per element of H and layer: with few rows per layer (the row shards of a round on
-    // 8 ranks: 512 rows each) that costs more than it saves, and the float32 kernel -- H as it stands, half the products
-    // when H is symmetric -- takes the batch.
-    const int f32_below = opt(OPT_ERROR_F32_BELOW) == 0 ? 1024 : opt(OPT_ERROR_F32_BELOW);
+    // planes first, 10 bytes of traffic per element of H and layer; until the end of round 2 a batch with fewer than 1024
+    // rows per layer (the row shards of a round on 8 ranks: 512 rows each) took the float32 kernel instead (H as it
+    // stands).  Measured again after the non-symmetric route and the banded splits: the bfloat16 kernel wins at every
+    // shard size by now (a rank of 8: 4.31 -> 4.14 ms per round; OPT-125M ... BLOOM-560M shards 0.5-1.5 %), so the
+    // threshold is a switch that is off by default ("error_f32_below" = rows).
+    const int f32_below = opt(OPT_ERROR_F32_BELOW) > 0 ? opt(OPT_ERROR_F32_BELOW) : 0;
     const bool few_rows = G == nullptr && batch > 1 && rpl < f32_below;
     const size_t d_plane = (size_t)n_rt * T32 * n;  // rows padded to whole tiles
     unsigned short *Dp = ws.take<unsigned short>(3 * d_plane), *Hp = ws.take<unsigned short>(3 * (size_t)n * n * batch);

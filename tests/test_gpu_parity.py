@@ -961,6 +961,11 @@ def test_batch_entry_points(amd, B, R, n, levels):
         for b in range(B):
             q1, i1, _ = eng.run_loop(W[b], None if scale is None else scale[b], facs[b][0], facs[b][1], abi, 32, 8, unscale=unscale)
             assert torch.equal(Q[b], q1) and torch.equal(idx[b], i1), (b, unscale)
+        # the 32-row window workgroups (two row sets per chain wave; a tile of 32 rows never straddles two layers of a
+        # stack: rows per layer are a multiple of 64): the same bits, uniform and table codebooks alike
+        with amd.lib.option("window_rows", 32):
+            Q32, idx32 = eng.run_loop_batch(W, scale, order, U, abi, 32, 8, unscale=unscale)
+        assert torch.equal(Q32, Q) and torch.equal(idx32, idx), unscale
     if R % 128:  # 64-row shards: the loop batches (tiles of 64), the error entry needs 128
         with pytest.raises(RuntimeError, match="multiple of 128"):
             eng.row_errors_batch(W, W, Hs)

@@ -65,7 +65,7 @@ typedef void *slk_stream_t;
  * (slk_gptq_quantize_batch, slk_row_errors_batch, slk_workspace_bytes_batch) and slk_symmetry_flag; 4 adds the
  * `trace` and `gains` arguments of slk_local_search, slk_set_option / slk_get_option and the batched factorisation
  * (slk_hessian_prepare_batch, slk_chol_inverse_upper_batch, slk_factor_workspace_bytes_batch); 5 adds codebook training
- * (slk_codebook_stats, slk_sort_f32, slk_unique_f32).                                                          */
+ * (slk_codebook_stats, slk_sort_f32, slk_unique_f32) and slk_local_search_batch.                                                          */
 int slk_abi_version(void);
 const char *slk_last_error(void);
 /* Run-time switches between code paths that give the same results (the tests hold them to that) or that shape a
@@ -257,6 +257,14 @@ int slk_symmetry_flag(const float *H, int n, int *flag, slk_stream_t stream);
 int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
                      double hi, const float *table, int moves, uint8_t *idx, int *trace, float *gains,
                      int gains_mode, void *workspace, size_t ws_bytes, slk_stream_t stream);
+/* The same search over `batch` layers of one shape stacked by rows (rows [b R, (b + 1) R) of W, Q, idx against H[b], a
+ * HOST array of `batch` device pointers; R = rows_per_layer, a multiple of 128 when batch > 1): the results of `batch`
+ * separate calls bit for bit, in ONE product and ONE launch of moves -- the row shards of a round on several ranks (a few
+ * hundred rows per layer) are bound by the host's launch rate otherwise.  symmetric: as in slk_row_errors_batch (may be NULL).
+ * Workspace: slk_workspace_bytes_batch(batch, rows_per_layer, n).                                                     */
+int slk_local_search_batch(const float *W, float *Q, const float *const *H, int batch, int rows_per_layer, int n,
+                           int levels, double lo, double hi, const float *table, int moves, uint8_t *idx,
+                           const int *symmetric, void *workspace, size_t ws_bytes, slk_stream_t stream);
 
 /* Scale selection: the callers' pre-step -------------------------- */
 /* compute_non_saturating_scaling (sleekit/scaling.py:44-55): scale[r] = max(max_r / hi_code,

@@ -131,7 +131,7 @@ size_t slk_workspace_bytes_batch(int batch, int rows_per_layer, int n) {
     if (batch < 1 || batch > 64 || rows_per_layer < 0 || n <= 0 || (long long)batch * rows_per_layer > 0x7fffffffLL) return 0;
     // the stacked rows as one layer, plus the operand planes of the other Hessians and the other inverse orders
     return slk_workspace_bytes(batch * rows_per_layer, n) + (size_t)(batch - 1) * 6 * (size_t)n * n +
-           (size_t)batch * n * sizeof(int) + 4096;
+           (size_t)batch * n * (sizeof(int) + sizeof(float)) + 4096;  // (+ every layer's diagonal for a batched local search)
 }
 
 int slk_probe_mfma_f64(double *sink, int blocks, int iters, slk_stream_t stream) {

@@ -108,6 +108,11 @@ struct PtrTable {
     const float *p[64];
 };
 
+// the layer error of a stack of `batch` layers (rows [b rpl, (b + 1) rpl) against Hs[b]) WITH the products G = (Q - W) H
+// the local search starts from (sgemm.hip; the public entries are slk_row_errors / slk_row_errors_batch)
+int row_errors_products(const float *W, const float *Q, const float *const *Hs, int batch, int rpl, int n, const int *sym_known,
+                        float *row_err, float *G, void *workspace, size_t ws_bytes, slk_stream_t stream);
+
 static inline hipStream_t as_stream(slk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

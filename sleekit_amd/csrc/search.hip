@@ -42,19 +42,22 @@ __device__ __forceinline__ Best wave_best(Best x) {
     return x;
 }
 
-__global__ void k_extract_diag(const float *__restrict__ H, int n, float *__restrict__ d) {
+__global__ void k_extract_diag(PtrTable hs, int n, float *__restrict__ d) {  // blockIdx.y: the layer of a stack
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) d[i] = H[(size_t)i * n + i];
+    if (i < n) d[(size_t)blockIdx.y * n + i] = hs.p[blockIdx.y][(size_t)i * n + i];
 }
 
 // trace (may be NULL): moves ints per row, 2 * column + (1 = up, 0 = down) of every move taken, -1 from the
 // first move on at which the row had nothing left to gain (or only a "move" onto the value it already has).
 template <int EPT>
 __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ W, float *__restrict__ Q,
-                                                      const float *__restrict__ H, const float *__restrict__ G,
+                                                      PtrTable hs, int rpl, const float *__restrict__ G,
                                                       const float *__restrict__ hdiag, int R, int n, Grid g,
                                                       int moves, uint8_t *__restrict__ idx, int *__restrict__ trace,
                                                       float *__restrict__ gains, int gains_mode) {
+    // (a stack of layers by rows: rows [b rpl, (b + 1) rpl) search against Hessian b)
+    const float *__restrict__ H = hs.p[blockIdx.x / rpl];
+    hdiag += (size_t)(blockIdx.x / rpl) * n;
     __shared__ Best red_up[4], red_dn[4];
     __shared__ HeapSum plan;
     extern __shared__ float terms[];  // heap_sum_floats(n): the products of the interaction sum, staged for NumPy's order
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 // and no staging of the products: 684 -> 532 us for 4096 x 4096 with 10 moves, 242 -> 184 for 1024 x 4096.
 template <int M8, int S, int WAVES>
 __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restrict__ W, float *__restrict__ Q,
-                                                           const float *__restrict__ H, const float *__restrict__ G,
+                                                           PtrTable hs, int rpl, const float *__restrict__ G,
                                                            const float *__restrict__ hdiag, int R, int n, Grid g, int moves,
                                                            uint8_t *__restrict__ idx, int *__restrict__ trace,
                                                            float *__restrict__ gains, int gains_mode) {
@@ -216,6 +219,8 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row = WAVES == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
     if (row >= R) return;  // (WAVES == 1: whole waves, and no barrier anywhere below; WAVES == 4: the whole workgroup)
+    const float *__restrict__ H = hs.p[row / rpl];  // a stack of layers by rows (a wave's row belongs to one layer)
+    hdiag += (size_t)(row / rpl) * n;
     const int m = 8 * M8;
     const int tr = WAVES == 1 ? lane : threadIdx.x;  // thread within the row
     const size_t base = (size_t)row * n;
@@ -346,29 +351,32 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
 
 using namespace slk;
 
-extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
-                                double hi, const float *table, int moves, uint8_t *idx, int *trace, float *gains,
-                                int gains_mode, void *workspace, size_t ws_bytes, slk_stream_t stream) {
-    SLK_REQUIRE(W && Q && H && R > 0 && n > 0 && moves >= 0, "bad arguments");
-    SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
-    SLK_REQUIRE(idx == nullptr || levels <= 256, "uint8 indices need levels <= 256");
-    SLK_REQUIRE(n <= 256 * 64, "local search supports n <= 16384");
-    SLK_REQUIRE(gains_mode >= 0 && gains_mode <= 2 && (gains_mode == 0 || gains), "gains_mode 1 / 2 needs the gains buffer");
+// One search over `batch` layers stacked by rows (rows [b rpl, (b + 1) rpl) against H[b]): the initial interaction product
+// is ONE batched product (row_errors_impl), the moves ONE launch -- the row shards of a round on several ranks are a few
+// hundred rows per layer, and a search per layer is ten launches of a few microseconds each (the host's launch rate
+// then bounds the rank: BLOOM-560M on 8 ranks spent 18 of its 34 ms per step enqueueing).
+static int local_search_impl(const float *W, float *Q, const float *const *Hs, int batch, int rpl, int n, int levels, double lo,
+                             double hi, const float *table, int moves, uint8_t *idx, int *trace, float *gains,
+                             int gains_mode, const int *sym_known, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+    const int R = batch * rpl;
     Arena ws(workspace, ws_bytes);
     float *G = ws.take<float>((size_t)R * n);
     float *row_err = ws.take<float>((size_t)R);
-    float *hdiag = ws.take<float>((size_t)n);
+    float *hdiag = ws.take<float>((size_t)n * batch);
     if (!G || !row_err || !hdiag) {
         set_error("workspace too small");
         return SLK_E_WS;
     }
     const size_t used = align_up(ws.used, 256);
     if (gains_mode != 2) {  // (carried gains: no initial product)
-        int rc = slk_row_errors(W, Q, H, R, n, row_err, G, static_cast<char *>(workspace) + used, ws_bytes - used, stream);
+        int rc = row_errors_products(W, Q, Hs, batch, rpl, n, sym_known, row_err, G, static_cast<char *>(workspace) + used,
+                                              ws_bytes - used, stream);
         if (rc != SLK_OK) return rc;
     }
+    PtrTable hs;
+    for (int b = 0; b < 64; ++b) hs.p[b] = b < batch ? Hs[b] : nullptr;
     hipStream_t s = as_stream(stream);
-    SLK_RUN("extract_diag", 0, 8.0 * n, s, k_extract_diag<<<(n + 255) / 256, 256, 0, s>>>(H, n, hdiag));
+    SLK_RUN("extract_diag", 0, 8.0 * n * batch, s, k_extract_diag<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(hs, n, hdiag));
     const Grid g = make_grid(levels, lo, hi, table);
     const int ept = (n + 255) / 256;
     const size_t lds = (size_t)(n + 8 * (n / 128) + 8) * sizeof(float);  // heap_sum_floats(n)
@@ -376,7 +384,7 @@ extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R,
     do {                                                                                                            \
         SLK_LDS_OPT_IN(k_local_search<E>, lds);                                                                     \
         SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                       \
-                k_local_search<E><<<R, 256, lds, s>>>(W, Q, H, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode)); \
+                k_local_search<E><<<R, 256, lds, s>>>(W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode)); \
     } while (0)
     // regular row lengths (8 or 16 leaves of m <= 128 elements, m % 8 == 0): one wave per row, no LDS, no barrier
     {
@@ -396,7 +404,7 @@ extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R,
     if (regular && m8 == M8 && leaves == LEAVES) {                                                                      \
         SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                           \
                 k_local_search_wave<M8, S, WAVES><<<WAVES == 1 ? (R + 3) / 4 : R, 256, 0, s>>>(                         \
-                    W, Q, H, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode));                                 \
+                    W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode));                           \
         return SLK_OK;                                                                                                  \
     }
         if (R >= 2048 || wave_opt < 0) {  // a wave per row: 8 or 16 leaves
@@ -421,3 +429,31 @@ extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R,
 #undef SLK_LS
     return SLK_OK;
 }
+
+extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
+                                double hi, const float *table, int moves, uint8_t *idx, int *trace, float *gains,
+                                int gains_mode, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+    SLK_REQUIRE(W && Q && H && R > 0 && n > 0 && moves >= 0, "bad arguments");
+    SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(idx == nullptr || levels <= 256, "uint8 indices need levels <= 256");
+    SLK_REQUIRE(n <= 256 * 64, "local search supports n <= 16384");
+    SLK_REQUIRE(gains_mode >= 0 && gains_mode <= 2 && (gains_mode == 0 || gains), "gains_mode 1 / 2 needs the gains buffer");
+    return local_search_impl(W, Q, &H, 1, R, n, levels, lo, hi, table, moves, idx, trace, gains, gains_mode, nullptr, workspace, ws_bytes,
+                             stream);
+}
+
+extern "C" int slk_local_search_batch(const float *W, float *Q, const float *const *H, int batch, int rows_per_layer, int n,
+                                      int levels, double lo, double hi, const float *table, int moves, uint8_t *idx,
+                                      const int *symmetric, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+    SLK_REQUIRE(W && Q && H && rows_per_layer > 0 && n > 0 && moves >= 0, "bad arguments");
+    SLK_REQUIRE(batch >= 1 && batch <= 64, "batch must be 1..64");
+    SLK_REQUIRE(batch == 1 || rows_per_layer % 128 == 0, "a batch needs rows_per_layer to be a multiple of 128");
+    SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
+    SLK_REQUIRE(idx == nullptr || levels <= 256, "uint8 indices need levels <= 256");
+    SLK_REQUIRE(n <= 256 * 64, "local search supports n <= 16384");
+    SLK_REQUIRE((long long)batch * rows_per_layer <= 0x7fffffffLL, "too many rows");
+    for (int b = 0; b < batch; ++b) SLK_REQUIRE(H[b], "null Hessian in the batch");
+    return local_search_impl(W, Q, H, batch, rows_per_layer, n, levels, lo, hi, table, moves, idx, nullptr, nullptr, 0, symmetric, workspace,
+                             ws_bytes, stream);
+}
+

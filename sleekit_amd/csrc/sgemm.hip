@@ -726,3 +726,11 @@ int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, 
 }
 
 }  // extern "C"
+
+namespace slk {
+int row_errors_products(const float *W, const float *Q, const float *const *Hs, int batch, int rpl, int n, const int *sym_known,
+                        float *row_err, float *G, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+    return row_errors_impl(W, Q, Hs, batch, rpl, n, row_err, G, workspace, ws_bytes, stream, sym_known);
+}
+}  // namespace slk
+

@@ -285,12 +285,13 @@ class HipBackend:
         cb = eng.require_uniform(self.quantizer)
         want_idx = cb[0] <= 256  # (the kernels emit uint8 indices)
         if self.moves > 0:
-            # local search works in the scaled domain (engine.quantize_layer): scaled copy in, one search per layer
-            # (a workgroup per row each: already wide), de-scale on the way out
+            # local search works in the scaled domain (engine.quantize_layer): scaled copy in, ONE search over the stack
+            # (engine.local_search_batch: a search per layer is ten small launches, and the shards of a round on several
+            # ranks are a few hundred rows each), de-scale on the way out.  (Padding rows of a ragged shard search too:
+            # rows never interact, they are cut off below.)
             Ws = eng.rows_divide(W.view(B * Rp, n), sc.reshape(-1)).view(B, Rp, n) if sc is not None else W
             Q, idx = eng.run_loop_batch(Ws, None, order, U, cb, 32, 8, want_idx=want_idx)
-            for b, lay in enumerate(round_layers):
-                eng.local_search(Ws[b, :rows], Q[b, :rows], lay["H"], cb, self.moves, idx[b, :rows] if want_idx else None)
+            eng.local_search_batch(Ws, Q, [lay["H"] for lay in round_layers], cb, self.moves, idx if want_idx else None, known)
             if sc is not None:
                 Q = eng.rows_divide(Q.view(B * Rp, n), sc.reshape(-1), invert=True).view(B, Rp, n)
         else:

@@ -222,6 +222,22 @@ def local_search(W, Q, H, cb_abi, moves, idx=None, want_trace=False, gains=None,
     return trace
 
 
+def local_search_batch(W, Q, Hs, cb_abi, moves, idx=None, symmetric=None):
+    """local_search over a batch of layers stacked by rows: W, Q (B, R, n) (idx (B, R, n) uint8 or None), Hs a list of B
+    Hessians; in place on Q and idx, the results of B separate searches."""
+    import ctypes
+
+    B, R, n = W.shape
+    assert len(Hs) == B and W.is_contiguous() and Q.is_contiguous() and (idx is None or idx.is_contiguous())
+    levels, lo, hi, table = cb_abi
+    ws, ws_bytes = dev.workspace(R, n, batch=B)
+    ptrs = (ctypes.c_void_p * B)(*[dev.ptr(H) for H in Hs])
+    _lib.check(
+        _lib.lib.slk_local_search_batch(dev.ptr(W), dev.ptr(Q), ptrs, B, R, n, levels, lo, hi, dev.ptr(table), int(moves), dev.ptr(idx),
+                                        dev.ptr(symmetric), dev.ptr(ws), ws_bytes, dev.stream_handle())
+    )
+
+
 def rows_divide(x, scale, invert=False):
     R, n = x.shape
     out = torch.empty_like(x)

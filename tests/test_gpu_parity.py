@@ -970,6 +970,17 @@ def test_batch_entry_points(amd, B, R, n, levels):
         with pytest.raises(RuntimeError, match="multiple of 128"):
             eng.row_errors_batch(W, W, Hs)
         return
+    # the local search over the stack == a search per layer (the last layer's Hessian is not symmetric): values, indices
+    Q0, idx0 = eng.run_loop_batch(W, None, order, U, abi, 32, 8)
+    Qb, idxb = Q0.clone(), idx0.clone()
+    eng.local_search_batch(W, Qb, Hs, abi, 10, idxb)
+    moved = 0
+    for b in range(B):
+        q1, i1 = Q0[b].clone(), idx0[b].clone()
+        eng.local_search(W[b], q1, Hs[b], abi, 10, i1)
+        assert torch.equal(Qb[b], q1) and torch.equal(idxb[b], i1), b
+        moved += int((q1 != Q0[b]).sum())
+    assert moved > 0
     Q, _ = eng.run_loop_batch(W, sc, order, U, abi, 32, 8, unscale=True)
     err = eng.row_errors_batch(W, Q, Hs)
     flags = torch.cat([eng.symmetry_flag(H) for H in Hs])

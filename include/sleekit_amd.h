@@ -65,7 +65,7 @@ typedef void *slk_stream_t;
  * (slk_gptq_quantize_batch, slk_row_errors_batch, slk_workspace_bytes_batch) and slk_symmetry_flag; 4 adds the
  * `trace` and `gains` arguments of slk_local_search, slk_set_option / slk_get_option and the batched factorisation
  * (slk_hessian_prepare_batch, slk_chol_inverse_upper_batch, slk_factor_workspace_bytes_batch); 5 adds codebook training
- * (slk_codebook_stats, slk_sort_f32, slk_unique_f32) and slk_local_search_batch.                                                          */
+ * (slk_codebook_stats, slk_sort_f32, slk_unique_f32), slk_local_search_batch and slk_factor_unpack_upper_batch.                                                          */
 int slk_abi_version(void);
 const char *slk_last_error(void);
 /* Run-time switches between code paths that give the same results (the tests hold them to that) or that shape a
@@ -197,6 +197,12 @@ int slk_factor_unpack(const void *payload, int n, double *U, long long *order, i
  *     reused round after round: a third less traffic than rewriting the zeros).                          */
 int slk_factor_unpack_upper(const void *payload, int n, double *U, long long *order, int *info,
                             slk_stream_t stream);
+/*     ... and a round's payloads (a HOST array of `batch` device pointers) into stacked factors U (batch, n, n),
+ *     order (batch, n), info (batch) in one launch; verdict (may be NULL): (batch) int32, the word that FOLLOWS each
+ *     payload's slk_factor_payload_words(n) (sleekit_amd.dist appends the root's symmetry verdict of the layer's
+ *     Hessian there: the buffers must then be one word longer).                                            */
+int slk_factor_unpack_upper_batch(const void *const *payloads, int batch, int n, double *U, long long *order, int *info,
+                                  int *verdict, slk_stream_t stream);
 
 /* a5+a8+a9+a10  quantize_opt without local search  (sleekit/obq.py:106-137, 202-213)
  *     W: R x n float32.  scale: per-row divisor applied on load (NULL: W is used as is).

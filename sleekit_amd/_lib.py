@@ -58,6 +58,7 @@ PROTOTYPES = {
     "slk_factor_pack": (c_int, [P, P, P, c_int, P, P]),
     "slk_factor_unpack": (c_int, [P, c_int, P, P, P, P]),
     "slk_factor_unpack_upper": (c_int, [P, c_int, P, P, P, P]),
+    "slk_factor_unpack_upper_batch": (c_int, [P, c_int, c_int, P, P, P, P, P]),
     "slk_gptq_quantize": (
         c_int,
         [P, P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P],

@@ -228,6 +228,25 @@ __global__ __launch_bounds__(256) void k_pack_factor(const double *__restrict__ 
     for_each_upper_pair(n, [&](int i, int j) { tri[tri_offset(i, n) - i + j] = U[(size_t)i * n + j]; });
 }
 
+// A round's payloads into the stacked factors in ONE launch: blockIdx.y is the layer (payload pointers by value; U (B, n, n),
+// order (B, n), info (B) and -- when asked for -- verdict (B): the word AFTER the payload, the root's symmetry verdict of H).
+__global__ __launch_bounds__(256) void k_unpack_factor_batch(PtrTable payloads, int n, size_t words, double *__restrict__ U,
+                                                             long long *__restrict__ order, int *__restrict__ info,
+                                                             int *__restrict__ verdict) {
+    const long long *__restrict__ payload = reinterpret_cast<const long long *>(payloads.p[blockIdx.y]);
+    U += (size_t)blockIdx.y * n * n;
+    order += (size_t)blockIdx.y * n;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            info[blockIdx.y] = (int)payload[0];
+            if (verdict) verdict[blockIdx.y] = (int)payload[words];  // the word after slk_factor_pack's
+        }
+        for (int j = threadIdx.x; j < n; j += blockDim.x) order[j] = payload[1 + j];
+    }
+    const double *tri = reinterpret_cast<const double *>(payload + 1 + n);
+    for_each_upper_pair(n, [&](int i, int j) { U[(size_t)i * n + j] = tri[tri_offset(i, n) - i + j]; });
+}
+
 template <bool UPPER_ONLY>
 __global__ __launch_bounds__(256) void k_unpack_factor(const long long *__restrict__ payload, int n, double *__restrict__ U,
                                                        long long *__restrict__ order, int *__restrict__ info) {
@@ -400,6 +419,20 @@ int slk_factor_unpack_upper(const void *payload, int n, double *U, long long *or
     hipStream_t s = as_stream(stream);
     SLK_RUN("factor_unpack", 0, 4.0 * n * (n + 1.0) + 4.0 * n * (n + 1.0), s,
             k_unpack_factor<true><<<n < 2048 ? n : 2048, 256, 0, s>>>(static_cast<const long long *>(payload), n, U, order, info));
+    return SLK_OK;
+}
+
+int slk_factor_unpack_upper_batch(const void *const *payloads, int batch, int n, double *U, long long *order, int *info,
+                                  int *verdict, slk_stream_t stream) {
+    SLK_REQUIRE(U && order && info && payloads && n > 0 && batch >= 1 && batch <= 64, "bad arguments");
+    PtrTable t;
+    for (int b = 0; b < 64; ++b) {
+        SLK_REQUIRE(b >= batch || payloads[b], "null payload in the batch");
+        t.p[b] = b < batch ? static_cast<const float *>(payloads[b]) : nullptr;
+    }
+    hipStream_t s = as_stream(stream);
+    SLK_RUN("factor_unpack", 0, batch * 8.0 * n * (n + 1.0), s,
+            k_unpack_factor_batch<<<dim3(n < 2048 ? n : 2048, batch), 256, 0, s>>>(t, n, slk_factor_payload_words(n), U, order, info, verdict));
     return SLK_OK;
 }
 

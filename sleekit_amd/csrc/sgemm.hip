@@ -4,6 +4,8 @@
 // Both are dense contractions on v_mfma_f32_32x32x2_f32 through mfma32.h.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "mfma32.h"
 #include "mfma_bf16x3.h"
 
@@ -14,9 +16,7 @@ namespace slk {
 // multiplies by D again and reduces each row over the tile's 128 columns in a fixed
 // order (lane tree, then the two column waves); partial[r][tile] goes to scratch and a
 // second kernel adds the tiles left to right, so results are run-to-run identical.
-struct HPtrs {
-    const float *p[64];  // the Hessians of a batch of layers stacked by rows
-};
+using HPtrs = PtrTable;  // the Hessians of a batch of layers stacked by rows
 
 __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W, const float *__restrict__ Q,
                                                      const HPtrs hs, int R, int n,
@@ -158,10 +158,14 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
 // Rows beyond `rows` in the last block repeat the last row (never stored by the GEMM).  n % 32 == 0.
 // One pass at HBM speed; it takes all the splitting arithmetic out of the GEMM, where every element
 // would otherwise be split once per tile that uses it (32 times at n = 4096).
-__global__ __launch_bounds__(256) void k_split3(const float *__restrict__ x, const float *__restrict__ y, int rows, int n,
+// blockIdx.y: the layer of a stack (its own x, flag and planes: out + blockIdx.y * 3 * plane); one launch for a round's
+// Hessians -- eight 4 MB matrices split one by one are eight launches of 17 us each, bound by nothing but their number.
+__global__ __launch_bounds__(256) void k_split3(PtrTable xs, const float *__restrict__ y, int rows, int n,
                                                 unsigned short *__restrict__ out, size_t plane,
                                                 const int *__restrict__ sym_flag, int swz, int band_only) {
-    if (sym_flag && sym_flag[0] <= 0) return;
+    const float *__restrict__ x = xs.p[blockIdx.y];
+    out += (size_t)blockIdx.y * 3 * plane;
+    if (sym_flag && sym_flag[blockIdx.y] <= 0) return;
     const int ksteps = n / 32;
     const size_t quads = plane / 4;  // groups of four consecutive k
     for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (size_t)gridDim.x * blockDim.x) {
@@ -340,8 +344,10 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
 // flag[0] = 1 iff H is bit-wise symmetric (flag must be preset to 1).  One workgroup per pair of mirrored
 // 64 x 64 tiles (a triangular list of pairs): tile (bi, bj) goes to LDS through coalesced 16-byte loads, tile
 // (bj, bi) is read the same way and compared with the transpose out of LDS -- every element is read once.
-__global__ __launch_bounds__(256) void k_symmetry_flag(const float *__restrict__ H, int n, int *__restrict__ flag) {
+__global__ __launch_bounds__(256) void k_symmetry_flag(PtrTable hs, int n, int *__restrict__ flag) {
     __shared__ float tile[64][65];
+    const float *__restrict__ H = hs.p[blockIdx.y];  // blockIdx.y: the layer of a stack, with a flag of its own
+    flag += blockIdx.y;
     // pair index -> (bi >= bj)
     int bi = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
     while ((bi + 1) * (bi + 2) / 2 <= (int)blockIdx.x) ++bi;
@@ -445,11 +451,14 @@ __global__ __launch_bounds__(256) void k_hessian_tiles(float *__restrict__ H, co
 // X (T x n, tokens x features) -> the three bfloat16 pieces of its TRANSPOSE in the GEMM's slab order: slab
 // (128-feature block ib, 32-token step ks) is [feature in block][32 tokens], contiguous; tokens beyond T are
 // zero.  One workgroup per slab: 32 coalesced rows of 128 floats in, through LDS, 8 KB per plane out.
-__global__ __launch_bounds__(256) void k_split3_transposed(const float *__restrict__ X, int n, int T, int t_first, int t_count,
+__global__ __launch_bounds__(256) void k_split3_transposed(PtrTable xs, int n, int T, int t_first, int t_count,
                                                            unsigned short *__restrict__ out, size_t plane, int swz,
                                                            const int *__restrict__ skip_if_symmetric) {
     __shared__ float tile[32][T32 + 1];
-    if (skip_if_symmetric && skip_if_symmetric[0] > 0) return;  // (the layer error: a symmetric H is split as it stands)
+    // blockIdx.z: the layer of a stack (its own X, flag and planes)
+    const float *__restrict__ X = xs.p[blockIdx.z];
+    out += (size_t)blockIdx.z * 3 * plane;
+    if (skip_if_symmetric && skip_if_symmetric[blockIdx.z] > 0) return;  // (the layer error: a symmetric H is split as it stands)
     const int ib = blockIdx.x, ks = blockIdx.y;
     const int t = threadIdx.x;
     for (int e = t; e < 32 * T32; e += 256) {
@@ -559,6 +568,12 @@ using namespace slk;
 
 extern "C" {
 
+static PtrTable one_ptr(const float *p) {
+    PtrTable t;
+    for (int b = 0; b < 64; ++b) t.p[b] = b == 0 ? p : nullptr;
+    return t;
+}
+
 static int row_errors_impl(const float *W, const float *Q, const float *const *Hs, int batch, int rpl, int n, float *row_err,
                            float *G, void *workspace, size_t ws_bytes, slk_stream_t stream, const int *sym_known = nullptr) {
     const int R = batch * rpl;
@@ -598,8 +613,7 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     } else if (try_sym) {
         SLK_RUN("set_flag", 0, 4, s, k_set_flag<<<1, 64, 0, s>>>(sym, 1, batch));
         const int t64 = (n + 63) / 64;
-        for (int b = 0; b < batch; ++b)
-            SLK_RUN("symmetry_check", 0, 4.0 * n * n, s, k_symmetry_flag<<<t64 * (t64 + 1) / 2, 256, 0, s>>>(Hs[b], n, sym + b));
+        SLK_RUN("symmetry_check", 0, 4.0 * n * n * batch, s, k_symmetry_flag<<<dim3(t64 * (t64 + 1) / 2, batch), 256, 0, s>>>(hp, n, sym));
     }
     // the bfloat16 x 3 kernel when the shape allows (16-byte loads, whole tiles of columns).  Its operands are split into
     // planes first, 10 bytes of traffic per element of H and layer; until the end of round 2 a batch with fewer than 1024
@@ -629,15 +643,15 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
         SLK_LDS_OPT_IN(k_error_tiles_bf16<true>, sizeof(TileBf16DmaSmem));
         const int dma = !opt(OPT_NO_BF16_DMA);  // operands to LDS by global_load_lds (swizzled planes)
         SLK_RUN("error_split", 0, 14.0 * R * n, s,
-                k_split3<<<2048, 256, 0, s>>>(W, Q, R, n, Dp, d_plane, batch == 1 && !asym_mode ? sym : nullptr, dma, 0));
-        for (int b = 0; b < batch; ++b) {
-            SLK_RUN("error_split", 0, 10.0 * n * n, s,
-                    k_split3<<<2048, 256, 0, s>>>(Hs[b], nullptr, n, n, Hp + (size_t)b * 3 * n * n, (size_t)n * n, sym + b, dma,
-                                                  G == nullptr));
-            if (asym_mode)  // (returns at once when the flag says symmetric)
+                k_split3<<<2048, 256, 0, s>>>(one_ptr(W), Q, R, n, Dp, d_plane, batch == 1 && !asym_mode ? sym : nullptr, dma, 0));
+        {
+            // every layer's H in one launch each (blockIdx.y / z = layer)
+            const int split_blocks = (int)std::min<size_t>(2048, ((size_t)n * n / 4 + 255) / 256);
+            SLK_RUN("error_split", 0, 10.0 * n * n * batch, s,
+                    k_split3<<<dim3(split_blocks, batch), 256, 0, s>>>(hp, nullptr, n, n, Hp, (size_t)n * n, sym, dma, G == nullptr));
+            if (asym_mode)  // (a layer's blocks return at once when its flag says symmetric)
                 SLK_RUN("error_split_t", 0, 0, s,
-                        k_split3_transposed<<<dim3(n / T32, n / 32), 256, 0, s>>>(Hs[b], n, n, 0, n, Hp + (size_t)b * 3 * n * n,
-                                                                                 (size_t)n * n, dma, sym + b));
+                        k_split3_transposed<<<dim3(n / T32, n / 32, batch), 256, 0, s>>>(hp, n, n, 0, n, Hp, (size_t)n * n, dma, sym));
         }
         // flops as executed: six bfloat16 products per float32 product, over k <= j only (the definition of the
         // layer error, SURVEY.md 8d, counts 2 R n^2 float32 flops: a third of this, twice over)
@@ -679,7 +693,7 @@ int slk_symmetry_flag(const float *H, int n, int *flag, slk_stream_t stream) {
     hipStream_t s = as_stream(stream);
     const int t64 = (n + 63) / 64;
     SLK_RUN("set_flag", 0, 4, s, k_set_flag<<<1, 64, 0, s>>>(flag, 1, 1));
-    SLK_RUN("symmetry_check", 0, 4.0 * n * n, s, k_symmetry_flag<<<t64 * (t64 + 1) / 2, 256, 0, s>>>(H, n, flag));
+    SLK_RUN("symmetry_check", 0, 4.0 * n * n, s, k_symmetry_flag<<<t64 * (t64 + 1) / 2, 256, 0, s>>>(one_ptr(H), n, flag));
     return SLK_OK;
 }
 
@@ -706,7 +720,7 @@ int slk_hessian_accumulate(float *H, float *mean, const float *X, int n, int T, 
             const int cnt = T - t0 < chunk ? T - t0 : chunk, ksteps = (cnt + 31) / 32;
             const size_t plane = (size_t)n * ksteps * 32;
             SLK_RUN("hessian_split", 0, 10.0 * cnt * n, s,
-                    k_split3_transposed<<<dim3(m, ksteps), 256, 0, s>>>(X, n, T, t0, cnt, Xp, plane, dma, nullptr));
+                    k_split3_transposed<<<dim3(m, ksteps), 256, 0, s>>>(one_ptr(X), n, T, t0, cnt, Xp, plane, dma, nullptr));
             // the running-mean factor applies once per batch: later chunks add to what the first one scaled
             if (dma)
                 SLK_RUN("hessian_syrk_bf16", 6.0 * cnt * n * (n + (double)T32), 6.0 * cnt * n + 8.0 * n * n, s,

@@ -211,16 +211,16 @@ class HipBackend:
         U = self._ustacks.get(key)
         if U is None:
             U = self._ustacks[key] = torch.zeros((B, n, n), dtype=torch.float64, device=device)
+        import ctypes
+
         order = torch.empty((B, n), dtype=torch.int64, device=device)
         info = torch.empty(B, dtype=torch.int32, device=device)
-        for b, payload in enumerate(payloads):
-            _lib.check(_lib.lib.slk_factor_unpack_upper(dev.ptr(payload), n, U[b].data_ptr(), order[b].data_ptr(),
-                                                        info[b:b + 1].data_ptr(), dev.stream_handle()))
-        known = None
-        if self.with_error:
-            mark = self.payload_words(n) - 1
-            # (every rank runs the same backend settings, so with_error here means the roots packed real verdicts)
-            known = torch.stack([p[mark] for p in payloads]).to(torch.int32)
+        # (every rank runs the same backend settings, so with_error here means the roots packed real verdicts)
+        known = torch.empty(B, dtype=torch.int32, device=device) if self.with_error else None
+        ptrs = (ctypes.c_void_p * B)(*[dev.ptr(p) for p in payloads])
+        # one launch for the round's payloads (a launch per layer is bound by the number of launches: 16 us each)
+        _lib.check(_lib.lib.slk_factor_unpack_upper_batch(ptrs, B, n, dev.ptr(U), dev.ptr(order), dev.ptr(info), dev.ptr(known),
+                                                          dev.stream_handle()))
         return self._run_stacked(round_layers, lo, hi, order, U, info, known)
 
     # -- one rank, small layers: a round of same-shaped layers is factored AND looped in launches that cover them all

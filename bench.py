@@ -29,7 +29,8 @@ The JSON line also carries
                  thing, alone and as timed;
   latency_ms_single_layer   one isolated layer, start to finish (SURVEY.md 8e);
   asymmetric_H  the same workload with Hessians made by torch `X.T @ X` (not bit-symmetric, like the experiments' dumps):
-                 the layer error then cannot halve its work;
+                 the layer error then averages H with its transpose on the way into its operand planes to keep
+                 the half-product route;
   cpu_baseline  the NumPy oracle (bit-identical to the reference, tests/test_oracle_golden.py)
                  timed on this host for one layer of the workload, rank 0, N = 1 only.
 """
@@ -406,7 +407,7 @@ def main():
                    "note": "median of 5 after one warm-up: a single layer alone on the GPU through engine.quantize_layer + row_errors, host call to synchronize"}
 
     # ---- the same workload on Hessians that are NOT bit-symmetric (made by a library GEMM, like the experiments' dumps
-    #      of torch `inp @ inp.t()`): the layer error cannot halve its work then
+    #      of torch `inp @ inp.t()`): the layer error keeps its half-product route by averaging H with its transpose in the split
     asym = None
     if extras and not args.config:
         n = args.cols

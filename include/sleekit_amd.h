@@ -70,7 +70,7 @@ int slk_abi_version(void);
 const char *slk_last_error(void);
 /* Run-time switches between code paths that give the same results (the tests hold them to that) or that shape a
  * measurement: "no_window2", "no_fast_leaf", "no_defer", "win_dbg", "no_regular_search", "no_fast_search_div",
- * "no_error_splitk", "error_cb", "no_sym_error", "no_bf16_error", "no_bf16_dma", "no_bf16_hessian", "no_bf16_asym",
+ * "no_error_splitk", "error_cb", "no_sym_error", "no_bf16_error", "no_bf16_dma", "no_bf16_hessian", "no_bf16_asym", "no_sym_average",
  * "error_f32_below", "no_wave_search", "lookahead" (a factorisation forks the bulk of its outer updates onto a helper stream: for one layer
  * at a time; sleekit_amd.engine.quantize_layer sets it around its own factorisation), "window_rows" (16 or 32 rows per
  * window workgroup; 0 = 16) (case-insensitive,

@@ -80,6 +80,7 @@ enum Opt {
     OPT_NO_BF16_HESSIAN,       // Hessian accumulation: float32 MFMA kernel
     OPT_ERROR_F32_BELOW,       // layer error of a batch: float32 kernel when a layer has fewer rows than this (0: never, the default)
     OPT_NO_BF16_ASYM,          // layer error: an H that is not symmetric goes to the float32 kernel
+    OPT_NO_SYM_AVERAGE,        // layer error: an H that is not symmetric is NOT averaged with its transpose (planes of H^T, every k, instead)
     OPT_NO_WAVE_SEARCH,        // local search: the workgroup-per-row kernel for every row length
     OPT_LOOKAHEAD,             // factorisation: the bulk of an outer syrk on a helper stream, beside the next block's panels
     OPT_WINDOW_ROWS,           // window kernel: rows per workgroup, 16 (default) or 32 (half the CUs per launch, 1.55 times the duration)

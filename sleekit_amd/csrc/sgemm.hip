@@ -162,10 +162,14 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
 // Hessians -- eight 4 MB matrices split one by one are eight launches of 17 us each, bound by nothing but their number.
 __global__ __launch_bounds__(256) void k_split3(PtrTable xs, const float *__restrict__ y, int rows, int n,
                                                 unsigned short *__restrict__ out, size_t plane,
-                                                const int *__restrict__ sym_flag, int swz, int band_only) {
+                                                const int *__restrict__ sym_flag, int swz, int band_only, int average) {
     const float *__restrict__ x = xs.p[blockIdx.y];
     out += (size_t)blockIdx.y * 3 * plane;
-    if (sym_flag && sym_flag[blockIdx.y] <= 0) return;
+    // `average`: a square matrix that is NOT symmetric is split as (x + x^T) / 2 -- the quadratic form d x d^T, which is all
+    // the layer error wants of it, is the same for both, and the symmetric half-product route then serves every Hessian
+    // (the second read is a column gather: twice the time of this pass, a tenth of the products it saves)
+    const bool avg = average && sym_flag && sym_flag[blockIdx.y] <= 0;
+    if (sym_flag && sym_flag[blockIdx.y] <= 0 && !avg) return;
     const int ksteps = n / 32;
     const size_t quads = plane / 4;  // groups of four consecutive k
     for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (size_t)gridDim.x * blockDim.x) {
@@ -179,6 +183,10 @@ __global__ __launch_bounds__(256) void k_split3(PtrTable xs, const float *__rest
         const int row = min(rb * 128 + r, rows - 1);
         const size_t src = (size_t)row * n + ks * 32 + k4;
         float4_t v = *reinterpret_cast<const float4_t *>(x + src);
+        if (avg) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = 0.5f * (v[c] + x[(size_t)(ks * 32 + k4 + c) * n + row]);
+        }
         if (y) {
             const float4_t u = *reinterpret_cast<const float4_t *>(y + src);
 #pragma unroll
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
     const int layer = r0 / rpl;
     // H not symmetric (or not known to be): its planes then hold H^T (k_split3_transposed), every k is multiplied and
     // nothing counted twice -- when the caller asked for that (asym_mode); otherwise those rows are the float32 kernel's
-    const bool full_k = G != nullptr || sym_flag[layer] <= 0;
+    const bool full_k = G != nullptr || (sym_flag[layer] <= 0 && asym_mode != 2);  // (2: the planes hold (H + H^T) / 2)
     if (sym_flag[layer] <= 0 && !asym_mode) return;
     Hp += (size_t)layer * 3 * n * n;
     const int t = threadIdx.x;
@@ -627,7 +635,9 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     unsigned short *Dp = ws.take<unsigned short>(3 * d_plane), *Hp = ws.take<unsigned short>(3 * (size_t)n * n * batch);
     const int bf16_ok = try_sym && vec_ok && n % T32 == 0 && Dp && Hp && !opt(OPT_NO_BF16_ERROR) && !few_rows;
     // a Hessian that is NOT symmetric stays on the bfloat16 kernel too (planes of H^T, every k) unless K is cut into chunks
-    const int asym_mode = bf16_ok && cb == 0 && !opt(OPT_NO_BF16_ASYM);
+    // ... or, when only the error is wanted (no G), is AVERAGED with its transpose on the way into the planes (asym_mode 2):
+    // d H d^T = d ((H + H^T) / 2) d^T, so every Hessian takes the symmetric half-product route
+    const int asym_mode = !bf16_ok ? 0 : (G == nullptr && !opt(OPT_NO_SYM_AVERAGE)) ? 2 : (cb == 0 && !opt(OPT_NO_BF16_ASYM)) ? 1 : 0;
     if (batch > 1 && !few_rows && !(Dp && Hp)) {
         set_error("workspace too small for the operand planes of %d layers (slk_workspace_bytes_batch)", batch);
         return SLK_E_WS;
@@ -643,13 +653,14 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
         SLK_LDS_OPT_IN(k_error_tiles_bf16<true>, sizeof(TileBf16DmaSmem));
         const int dma = !opt(OPT_NO_BF16_DMA);  // operands to LDS by global_load_lds (swizzled planes)
         SLK_RUN("error_split", 0, 14.0 * R * n, s,
-                k_split3<<<2048, 256, 0, s>>>(one_ptr(W), Q, R, n, Dp, d_plane, batch == 1 && !asym_mode ? sym : nullptr, dma, 0));
+                k_split3<<<2048, 256, 0, s>>>(one_ptr(W), Q, R, n, Dp, d_plane, batch == 1 && !asym_mode ? sym : nullptr, dma, 0, 0));
         {
             // every layer's H in one launch each (blockIdx.y / z = layer)
             const int split_blocks = (int)std::min<size_t>(2048, ((size_t)n * n / 4 + 255) / 256);
             SLK_RUN("error_split", 0, 10.0 * n * n * batch, s,
-                    k_split3<<<dim3(split_blocks, batch), 256, 0, s>>>(hp, nullptr, n, n, Hp, (size_t)n * n, sym, dma, G == nullptr));
-            if (asym_mode)  // (a layer's blocks return at once when its flag says symmetric)
+                    k_split3<<<dim3(split_blocks, batch), 256, 0, s>>>(hp, nullptr, n, n, Hp, (size_t)n * n, sym, dma, G == nullptr,
+                                                                       asym_mode == 2));
+            if (asym_mode == 1)  // (a layer's blocks return at once when its flag says symmetric)
                 SLK_RUN("error_split_t", 0, 0, s,
                         k_split3_transposed<<<dim3(n / T32, n / 32, batch), 256, 0, s>>>(hp, n, n, 0, n, Hp, (size_t)n * n, dma, sym));
         }

@@ -508,16 +508,26 @@ def test_layer_error_bf16_path(amd, slkopt):
     slkopt.delenv("SLK_NO_ERROR_SPLITK")
     np.testing.assert_allclose(whole, want, rtol=1e-5)
     np.testing.assert_allclose(got, whole, rtol=2e-6)
-    # not symmetric: every k is multiplied -- on the bfloat16 MFMA from planes of H^T (default), on the float32 MFMA
-    # (switch), and with the K-chunked few-row layout (which sends such a layer to the float32 kernel)
+    # not symmetric: the error d H d^T only sees (H + H^T) / 2, which the split forms on the way into the planes, so the
+    # half-product route serves it too (default); or every k is multiplied -- on the bfloat16 MFMA from planes of H^T
+    # (first switch), on the float32 MFMA (both switches; also what the K-chunked few-row layout did before the average)
     Ha = (H + np.float32(0.05) * np.triu(rng.standard_normal((n, n)).astype(np.float32), 1)).astype(np.float32)
     Ha[3, 7] += np.float32(0.25)
     want_a = ((D @ Ha.astype(np.float64)) * D).sum(axis=1)
     got_a = amd.obq.channelwise_error(W, Q, Ha)
     np.testing.assert_allclose(got_a, want_a, rtol=1e-5)
+    slkopt.setenv("SLK_NO_SYM_AVERAGE", "1")
+    planes_t = amd.obq.channelwise_error(W, Q, Ha)
+    np.testing.assert_allclose(planes_t, want_a, rtol=1e-5)
+    np.testing.assert_allclose(planes_t, got_a, rtol=4e-6)
     slkopt.setenv("SLK_NO_BF16_ASYM", "1")
     np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, Ha), got_a, rtol=4e-6)
     slkopt.delenv("SLK_NO_BF16_ASYM")
+    slkopt.delenv("SLK_NO_SYM_AVERAGE")
+    for chunk in ("2", "8"):  # the K-chunked layout of few-row calls takes the averaged planes like any symmetric H
+        slkopt.setenv("SLK_ERROR_CB", chunk)
+        np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, Ha), want_a, rtol=1e-5)
+    slkopt.delenv("SLK_ERROR_CB")
     # the product itself (what the local search starts from): G = (W - Q) @ Ha, both routes
     Wd, Qd, Hd = (torch.from_numpy(x).cuda() for x in (W, Q, Ha))
     _, G1 = amd.engine.row_errors(Wd, Qd, Hd, want_G=True)

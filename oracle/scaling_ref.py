@@ -68,68 +68,69 @@ def grid_error(H, D):
     return ((D @ H) * D).sum(axis=-1)
 
 
-def best_grid_scale(data, grid, axis=0, H=None, min_factor=0.05, max_factor=1.0, grid_size=100):
-    rest = tuple(i for i in range(data.ndim) if i != axis)
-    flat = np.transpose(data, [axis, *rest])
-    base = no_clip_scale(flat, grid, 0)
-    factors = np.linspace(min_factor, max_factor, grid_size, dtype=np.float32)
-    pick = np.full(base.size, np.inf, dtype=np.float32)
-    best = np.full(base.size, np.inf, dtype=np.float32)
+def _first_best(base, factors, row_errors):
+    """The grid search shared by scaling.py:98-134 and 160-190: walk the factors in order, keep for every row the FIRST
+    factor whose error is strictly smaller than everything before it (float32 bookkeeping, both start at +inf)."""
+    chosen = np.full(base.size, np.inf, dtype=np.float32)
+    lowest = np.full(base.size, np.inf, dtype=np.float32)
     for f in factors:
-        q = quantize_scaled(flat, f * base, grid)
-        e = grid_error(H, q - flat)
-        better = e < best
-        best[better] = e[better]
-        pick[better] = f
-    return base * pick
+        e = row_errors(f * base)
+        improved = e < lowest
+        lowest[improved] = e[improved]
+        chosen[improved] = f
+    return base * chosen
+
+
+def _rows_first(data, axis):
+    others = tuple(i for i in range(data.ndim) if i != axis)
+    return np.transpose(data, [axis, *others])
+
+
+def best_grid_scale(data, grid, axis=0, H=None, min_factor=0.05, max_factor=1.0, grid_size=100):
+    flat = _rows_first(data, axis)
+    factors = np.linspace(min_factor, max_factor, grid_size, dtype=np.float32)
+    return _first_best(no_clip_scale(flat, grid, 0), factors, lambda sc: grid_error(H, quantize_scaled(flat, sc, grid) - flat))
 
 
 def best_obq_scale(
     data, grid, axis, H, damp=0.01, order_mode="diag", min_factor=0.05, max_factor=1.0, grid_size=100
 ):
-    rest = tuple(i for i in range(data.ndim) if i != axis)
-    W = np.transpose(data, [axis, *rest])
+    W = _rows_first(data, axis)
     base = no_clip_scale(W, grid, 0)
     n = H.shape[0]
     H_damped = H + damp * H.diagonal().mean() * np.eye(n)
     order = obq_ref.column_order(divide_rows(W, base, 0), H_damped, grid, order_mode)
+    # everything in processing order from here on, the error included (scaling.py:170-172)
     W = W[:, order]
     H = H[order][:, order]
     U = obq_ref.inverse_factor_upper(H_damped[order][:, order])
     ops = obq_ref.block_schedule(n, 32, 8)
-    factors = np.linspace(min_factor, max_factor, grid_size, dtype=np.float32)
-    pick = np.full(base.size, np.inf, dtype=np.float32)
-    best = np.full(base.size, np.inf, dtype=np.float32)
-    for f in factors:
-        sc = f * base
+
+    def loop_error(sc):
         Q = divide_rows(W, sc, 0)
-        E = np.zeros_like(W)
-        obq_ref.run_schedule(Q, E, U, grid, ops)
-        Q = divide_rows(Q, 1 / sc, 0)
-        e = grid_error(H, Q - W)
-        better = e < best
-        best[better] = e[better]
-        pick[better] = f
-    return base * pick
+        obq_ref.run_schedule(Q, np.zeros_like(W), U, grid, ops)
+        return grid_error(H, divide_rows(Q, 1 / sc, 0) - W)
+
+    return _first_best(base, np.linspace(min_factor, max_factor, grid_size, dtype=np.float32), loop_error)
 
 
 def pick_scale(data, grid, H, mode="mse", axis=0, min_factor=0.05, max_factor=1.0, grid_size=100):
-    if mode == "max":
-        return no_clip_scale(data, grid, axis)
-    if mode == "norm":
-        return norm_scale(data, axis)
-    kw = dict(grid_size=grid_size, min_factor=min_factor, max_factor=max_factor)
+    """scaling.py:193-238: "max" | "norm" | "obq" | "mse" | "hessian[N]" | "diag[N]" (N: per cent of the mean diagonal added)."""
+    search = dict(grid_size=grid_size, min_factor=min_factor, max_factor=max_factor)
+    if mode in ("max", "norm"):
+        return no_clip_scale(data, grid, axis) if mode == "max" else norm_scale(data, axis)
     if mode == "obq":
-        return best_obq_scale(data, grid, axis, H=H, **kw)
-    if mode == "mse":
-        H = None
-    elif mode.startswith("hessian"):
-        if len(mode) > 7:
-            H = H + 0.01 * float(mode[7:]) * H.diagonal().mean() * np.eye(H.shape[0])
-    elif mode.startswith("diag"):
-        H = H.diagonal()
-        if len(mode) > 4:
-            H = H + 0.01 * float(mode[4:]) * H.mean()
-    else:
+        return best_obq_scale(data, grid, axis, H=H, **search)
+    for family in ("hessian", "diag"):
+        if mode.startswith(family):
+            extra = mode[len(family):]
+            if family == "diag":
+                H = H.diagonal()
+                if extra:
+                    H = H + 0.01 * float(extra) * H.mean()
+            elif extra:
+                H = H + 0.01 * float(extra) * H.diagonal().mean() * np.eye(H.shape[0])
+            return best_grid_scale(data, grid, axis, H=H, **search)
+    if mode != "mse":
         raise RuntimeError(f"Unknown scaling mode {mode}")
-    return best_grid_scale(data, grid, axis, H=H, **kw)
+    return best_grid_scale(data, grid, axis, H=None, **search)

@@ -1,15 +1,18 @@
-"""Drop-in for `sleekit.statistics.Sleekit`: running layer statistics and layer quantization on the GPU.
+"""`Sleekit`: the GPTQ-style layer adapter of the reference (sleekit/statistics.py:12-199), kept on the GPU.
 
-Interface of the reference class (sleekit/statistics.py:12-199, "API compatible with GPTQ"):
-`Sleekit(layer).add_batch(inp)`, `.quantize(nbits, ...)`, the three presets, `.export(path)`, `.free()`.
+    st = Sleekit(layer); st.add_batch(x) ...; st.quantize_sleekit_light(3)      # or .quantize(nbits, ...)
 
-* `add_batch` (statistics.py:76-87) runs on the matrix cores through `slk_hessian_accumulate` (float32-grade
-  products of bfloat16 pieces when the feature count is a multiple of 128, float32 MFMA otherwise); the mean
-  and the Hessian live on the layer's device and never visit the host.  Conv1d / Conv2d inputs are
-  unfolded with `torch.nn.functional.unfold` exactly as the reference does (statistics.py:44-69) --
-  data movement, not arithmetic -- and then take the same kernel.
-* `quantize` (statistics.py:146-190) = scale selection + the device pipeline + bias correction, with
-  no `.numpy()` round trip (the reference moves everything to the host at statistics.py:162-166).
+What each piece maps to:
+
+* `add_batch` -- the running mean and Hessian of statistics.py:76-87 -- is ONE call of `slk_hessian_accumulate`
+  per batch (float32-grade products of bfloat16 pieces on the matrix cores when the feature count is a multiple
+  of 128, the float32 MFMA otherwise).  Samples are handed over as ROWS (T, n); the reference holds them as
+  columns (n, T): same statistics.  Convolutions are seen through `torch.nn.functional.unfold` like there
+  (statistics.py:44-69): pure data movement.
+* `quantize` (statistics.py:146-190): scale selection (`sleekit_amd.scaling.compute_scaling`), the device
+  pipeline (`engine.quantize_layer`) and the bias correction `bias += ((W - Q) * mean).sum(1)`, all on device
+  tensors -- the reference goes through `.numpy()` for every one of them (statistics.py:162-166).
+* the three presets (statistics.py:107-144) are rows of `_PRESETS`.
 """
 
 import os
@@ -24,119 +27,122 @@ from . import engine
 from .codebook import UniformCodebook
 from .scaling import compute_scaling
 
+_SUPPORTED = (nn.Linear, nn.Conv1d, nn.Conv2d)
+
+# keyword arguments of Sleekit.quantize behind quantize_<name>(nbits)
+_PRESETS = {
+    "basic": dict(scaling_mode="mse", order_mode="diag", bias_correction=False, damp=0.01, nb_ls_moves=0),
+    "sleekit_light": dict(scaling_mode="diag", order_mode="sqerr", bias_correction=True, damp=0.03, nb_ls_moves=0),
+    "sleekit_heavy": dict(scaling_mode="hessian", order_mode="sqerr", bias_correction=True, damp=0.03, nb_ls_moves=100),
+}
+_PRESET_NOTES = {
+    "basic": "plain GPTQ-like settings, none of the improvements (statistics.py:107-118)",
+    "sleekit_light": 'the "light" recipe (statistics.py:120-131)',
+    "sleekit_heavy": 'the "heavy" recipe, 100 local-search moves (statistics.py:133-144)',
+}
+
+
+def _windows_as_rows(x, layer):
+    """Every receptive field of a convolution as one row of length channels * prod(kernel) (statistics.py:44-69)."""
+    kernel, dilation, padding, stride = layer.kernel_size, layer.dilation, layer.padding, layer.stride
+    if isinstance(layer, nn.Conv1d):
+        # a (k, 1) two-dimensional convolution over a trailing axis of length one
+        x = x[None] if x.ndim == 2 else x
+        x = x[..., None]
+        kernel, dilation, padding, stride = (kernel[0], 1), (dilation[0], 1), (padding[0], 0), (stride[0], 1)
+    elif x.ndim == 3:
+        x = x[None]
+    cols = F.unfold(x, kernel, dilation, padding, stride)  # (batch, features, positions)
+    return cols.transpose(1, 2).reshape(-1, cols.shape[1])
+
+
+def _preset_method(name):
+    def run(self, nbits):
+        return self.quantize(nbits, **_PRESETS[name])
+
+    run.__name__ = "quantize_" + name
+    run.__doc__ = f"quantize(nbits) with {_PRESET_NOTES[name]}."
+    return run
+
 
 class Sleekit:
-    """Statistics of a layer, with the GPTQ-compatible interface of the reference."""
+    """Running statistics of one layer's inputs and its quantization; interface of the reference's class."""
 
     def __init__(self, layer):
-        self.layer = layer
-        if not isinstance(self.layer, (nn.Linear, nn.Conv1d, nn.Conv2d)):
-            raise ValueError(f"Unsupported layer type {type(self.layer)}")
+        if not isinstance(layer, _SUPPORTED):
+            raise ValueError(f"Unsupported layer type {type(layer)}")
         if not layer.weight.is_cuda:
             raise RuntimeError("sleekit_amd.Sleekit accumulates on the GPU: move the layer to the device first")
-        weight = layer.weight
-        if isinstance(self.layer, (nn.Conv1d, nn.Conv2d)):
-            weight = weight.flatten(1)
-        n = weight.shape[1]
-        self.mean = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.hessian = torch.zeros((n, n), dtype=torch.float32, device=self.device)
+        self.layer = layer
+        features = layer.weight[0].numel()  # columns of the weight seen as an (out, features) matrix
         self.count = 0
+        self.mean = torch.zeros(features, dtype=torch.float32, device=self.device)
+        self.hessian = torch.zeros((features, features), dtype=torch.float32, device=self.device)
 
     @property
     def device(self):
         return self.layer.weight.device
 
     def _prepare_input(self, inp):
-        """Activations -> (T, n) float32 samples, one per ROW (statistics.py:37-74).
-
-        The reference produces (n, T); the kernel reads samples as rows, so the transposes differ
-        but the statistics are the same.
-        """
-        inp = inp.to(self.device)
-        if isinstance(self.layer, nn.Linear):
-            inp = inp.reshape((-1, inp.shape[-1]))
-        elif isinstance(self.layer, nn.Conv2d):
-            if inp.ndim == 3:
-                inp = torch.unsqueeze(inp, 0)
-            inp = F.unfold(inp, self.layer.kernel_size, self.layer.dilation, self.layer.padding, self.layer.stride)
-            inp = inp.permute([0, 2, 1]).flatten(0, 1)  # (batch * positions, channels * k * k)
-        else:  # Conv1d: unfold as a (k, 1) 2-D convolution, like the reference
-            if inp.ndim == 2:
-                inp = torch.unsqueeze(inp, 0)
-            inp = torch.unsqueeze(inp, -1)
-            inp = F.unfold(
-                inp, (self.layer.kernel_size[0], 1), (self.layer.dilation[0], 1), (self.layer.padding[0], 0),
-                (self.layer.stride[0], 1),
-            )
-            inp = inp.permute([0, 2, 1]).flatten(0, 1)
-        assert inp.ndim == 2
-        return inp.float().contiguous()
+        """(T, features) float32 samples of a batch of activations, one per row (statistics.py:37-74 gives the transpose)."""
+        x = inp.to(self.device)
+        rows = x.reshape(-1, x.shape[-1]) if isinstance(self.layer, nn.Linear) else _windows_as_rows(x, self.layer)
+        assert rows.ndim == 2
+        return rows.float().contiguous()
 
     def add_batch(self, inp, out=None):
-        """Fold a batch into the running mean and Hessian (statistics.py:76-87)."""
-        X = self._prepare_input(inp)
-        T, n = X.shape
-        assert n == self.mean.shape[0]
-        ws, ws_bytes = dev.workspace(0, n)
-        _lib.check(
-            _lib.lib.slk_hessian_accumulate(
-                dev.ptr(self.hessian), dev.ptr(self.mean), dev.ptr(X), n, T, int(self.count), dev.ptr(ws), ws_bytes,
-                dev.stream_handle(),
-            )
-        )
-        self.count += T
+        """mean <- mean c / (c + T) + sum / (c + T), hessian likewise with X^T X: statistics.py:76-87, one kernel call."""
+        samples = self._prepare_input(inp)
+        tokens, features = samples.shape
+        assert features == self.mean.numel()
+        scratch, scratch_bytes = dev.workspace(0, features)
+        rc = _lib.lib.slk_hessian_accumulate(dev.ptr(self.hessian), dev.ptr(self.mean), dev.ptr(samples), features, tokens,
+                                             int(self.count), dev.ptr(scratch), scratch_bytes, dev.stream_handle())
+        _lib.check(rc)
+        self.count += tokens
 
     def export(self, path, npy_format=False):
-        """Dump bias / weight / mean / hessian as .pt or .npy, the files the experiments read (statistics.py:89-105)."""
+        """bias / weight / mean / hessian as four .pt (or .npy) files in `path`: what the experiments load (statistics.py:89-105)."""
         os.makedirs(path, exist_ok=True)
-        items = dict(bias=self.layer.bias, weight=self.layer.weight, mean=self.mean, hessian=self.hessian)
-        for name, t in items.items():
+        for name in ("bias", "weight", "mean", "hessian"):
+            value = getattr(self.layer, name) if name in ("bias", "weight") else getattr(self, name)
+            host = value.detach().cpu()
             if npy_format:
                 import numpy as np
 
-                np.save(os.path.join(path, name + ".npy"), t.detach().cpu().numpy())
+                np.save(os.path.join(path, f"{name}.npy"), host.numpy())
             else:
-                torch.save(t.detach().cpu(), os.path.join(path, name + ".pt"))
+                torch.save(host, os.path.join(path, f"{name}.pt"))
 
-    def quantize_basic(self, nbits):
-        """A typical quantization method, without the improvements (statistics.py:107-118)."""
-        return self.quantize(nbits, scaling_mode="mse", order_mode="diag", bias_correction=False, damp=0.01, nb_ls_moves=0)
-
-    def quantize_sleekit_light(self, nbits):
-        """Sleekit "light" (statistics.py:120-131)."""
-        return self.quantize(nbits, scaling_mode="diag", order_mode="sqerr", bias_correction=True, damp=0.03, nb_ls_moves=0)
-
-    def quantize_sleekit_heavy(self, nbits):
-        """Sleekit "heavy" (statistics.py:133-144)."""
-        return self.quantize(nbits, scaling_mode="hessian", order_mode="sqerr", bias_correction=True, damp=0.03, nb_ls_moves=100)
+    quantize_basic = _preset_method("basic")
+    quantize_sleekit_light = _preset_method("sleekit_light")
+    quantize_sleekit_heavy = _preset_method("sleekit_heavy")
 
     def quantize(self, nbits, scaling_mode="mse", order_mode="diag", bias_correction=False, damp=0.01, nb_ls_moves=0,
                  grid_size=100, min_factor=0.05, max_factor=1.0, scale=None):
-        """Quantize the layer in place to `nbits` (statistics.py:146-190).
+        """The layer's weight replaced by its `nbits` quantization, in place (statistics.py:146-190).
 
-        `scale` (optional, (out,) float32): skip the scale search and use this per-row scale.
+        bias_correction: quantize against H - mean mean^T and move the expected output shift into the bias.
+        `scale` (optional, (out,) float32): this per-row scale instead of the scale search.
         """
-        cb = UniformCodebook(2**nbits, -1, 1)
+        codebook = UniformCodebook(2**nbits, -1, 1)
+        weight = self.layer.weight.data.flatten(1).float().contiguous()
         H = self.hessian
         if bias_correction:
-            Hc = torch.empty_like(H)
-            _lib.check(
-                _lib.lib.slk_hessian_strip_mean(dev.ptr(H), dev.ptr(self.mean), H.shape[0], dev.ptr(Hc), dev.stream_handle())
-            )
-            H = Hc
-        weight = self.layer.weight.data.flatten(1).float().contiguous()
+            centred = torch.empty_like(H)
+            _lib.check(_lib.lib.slk_hessian_strip_mean(dev.ptr(H), dev.ptr(self.mean), H.shape[0], dev.ptr(centred), dev.stream_handle()))
+            H = centred
         if scale is None:
-            scale = compute_scaling(weight, cb, H=H, mode=scaling_mode, grid_size=grid_size, min_factor=min_factor,
+            scale = compute_scaling(weight, codebook, H=H, mode=scaling_mode, grid_size=grid_size, min_factor=min_factor,
                                     max_factor=max_factor)
-        res = engine.quantize_layer(weight, H, cb, dev.to_device(scale), order_mode, damp, nb_ls_moves)
-        self.layer.weight.data = res.Q.reshape(self.layer.weight.shape).to(self.layer.weight.dtype)
+        result = engine.quantize_layer(weight, H, codebook, dev.to_device(scale), order_mode, damp, nb_ls_moves)
+        target = self.layer.weight
+        target.data = result.Q.reshape(target.shape).to(target.dtype)
         if bias_correction:
-            delta = ((weight - res.Q) * self.mean).sum(dim=1)
-            self.layer.bias.data += delta.to(self.layer.bias.dtype)
-        return res
+            shift = ((weight - result.Q) * self.mean).sum(dim=1)
+            self.layer.bias.data += shift.to(self.layer.bias.dtype)
+        return result
 
     def free(self):
-        self.layer = None
-        self.mean = None
-        self.hessian = None
+        self.layer = self.mean = self.hessian = None
         self.count = 0

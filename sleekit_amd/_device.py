@@ -87,22 +87,33 @@ def release_workspaces():
     _workspaces.clear()
 
 
-def note_info(info, what):
-    """Register the status word of a factorisation; raise now unless lazy_errors is set."""
-    if lazy_errors:
+def note_info(info, what, defer=False):
+    """Register the status word of a factorisation; raise now unless lazy_errors is set (or `defer`: the word is
+    still in flight on another stream -- check with raise_pending() after synchronising)."""
+    if lazy_errors or defer:
         _pending_info.append((info, what))
         return
     _raise_if_failed(info, what)
 
 
+def raise_not_pd(code, what):
+    """numpy.linalg.LinAlgError, what np.linalg.cholesky raises in the reference (sleekit/obq.py:49-50)."""
+    raise np.linalg.LinAlgError(f"{what}: Matrix is not positive definite (pivot {code - 1})")
+
+
 def _raise_if_failed(info, what):
     code = int(info.item())
     if code != 0:
-        raise np.linalg.LinAlgError(f"{what}: Matrix is not positive definite (pivot {code - 1})")
+        raise_not_pd(code, what)
 
 
 def raise_pending():
+    """Check every status word registered since the last call (one device -> host read for all of them)."""
     pending, _pending_info[:] = list(_pending_info), []
-    for info, what in pending:
-        _raise_if_failed(info, what)
+    if not pending:
+        return
+    codes = torch.cat([info.reshape(-1)[:1] for info, _ in pending]).cpu().tolist()
+    for code, (_, what) in zip(codes, pending):
+        if code != 0:
+            raise_not_pd(code, what)
 

@@ -170,6 +170,29 @@ class HipBackend:
             factor = factor + (eng.symmetry_flag(H),)
         return factor
 
+    def note_statuses(self, infos, layers, defer=False):
+        """The status words of the layers' factorisations (0, or 1 + the failing pivot), one per layer of the stream:
+        LinAlgError like the reference's np.linalg.cholesky (sleekit/obq.py:49-50), naming the layer -- now (ONE read
+        of all the words), or at _device.raise_pending() when deferred (the words may still be in flight on a side
+        stream) or when _device.lazy_errors is set."""
+        from . import _device as dev
+
+        def label(l):
+            R, n = layers[l]["W"].shape
+            return f"quantize_stream: layer {l} ({R} x {n}), compute_hessian_chol"
+
+        have = [l for l, info in enumerate(infos) if info is not None]
+        if not have:
+            return
+        if defer or dev.lazy_errors:
+            for l in have:
+                dev.note_info(infos[l], label(l), defer=True)
+            return
+        codes = torch.cat([infos[l].reshape(1) for l in have]).cpu().tolist()
+        for l, code in zip(have, codes):
+            if code != 0:
+                dev.raise_not_pd(code, label(l))
+
     def run_rows(self, layer, lo, hi, factor):
         eng = self.engine
         W = layer["W"][lo:hi].contiguous()
@@ -399,7 +422,7 @@ def _quantize_stream_local(layers, small, short, backend, join):
     taken = set(small) | set(short)
     rest = [l for l in range(n_layers) if l not in taken]
     if rest:
-        for l, shard in zip(rest, quantize_stream([layers[l] for l in rest], backend, join=join, _local=False)):
+        for l, shard in zip(rest, _quantize_stream([layers[l] for l in rest], backend, join=join, _local=False)):
             out[l] = shard
     if join and here is not None:
         for st in pool:
@@ -419,7 +442,24 @@ def _short_rounds(layers, short, backend):
     return rounds
 
 
-def quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
+def quantize_stream(layers, backend, comm_device=None, join=True):
+    """Quantize `layers` (see _quantize_stream) and REGISTER every layer's factorisation status.
+
+    A Hessian that is not positive definite makes the reference raise numpy.linalg.LinAlgError
+    (sleekit/obq.py:49-50, np.linalg.cholesky).  Here the status word of every layer's factorisation --
+    made on this rank, or carried by the packed factor another rank sent -- is handed to the backend
+    (`backend.note_status`): HipBackend raises LinAlgError naming the layer, at once when `join` is true and
+    sleekit_amd._device.lazy_errors is off (the default), otherwise at `_device.raise_pending()`.  Every rank sees
+    every layer's status, so every rank raises.
+    """
+    out = _quantize_stream(layers, backend, comm_device, join, True)
+    note = getattr(backend, "note_statuses", None)
+    if note is not None:
+        note([None if shard is None else shard.get("info") for shard in out], layers, defer=not join)
+    return out
+
+
+def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
     """Quantize `layers` (list of dicts with W (R, n), H (n, n), optional scale (R,)) across the ranks.
 
     Returns, per layer, this rank's shard: dict(Q, idx, row_err, rows=(lo, hi), info).

@@ -53,6 +53,18 @@ def main():
             assert int(sh["info"].item()) == 0
     # bucketed by shape: rounds (0, 3), (1, 4) and the ragged (2, 5) -- padded to whole tiles -- batched; (6) alone
     assert calls["round"] == 4 * 3 and calls["rows"] == 4 * 1, calls
+    # an indefinite Hessian in a batched round: its root's status word travels in the packed factor, and EVERY rank
+    # raises LinAlgError naming the layer (reference: np.linalg.cholesky, sleekit/obq.py:49-50)
+    bad = [dict(lay) for lay in layers]
+    bad[4]["H"] = bad[4]["H"].clone()
+    bad[4]["H"][11, 11] = -3.0
+    backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True)
+    try:
+        sdist.quantize_stream(bad, backend)
+    except np.linalg.LinAlgError as exc:
+        assert "layer 4 (512 x 1024)" in str(exc), str(exc)
+    else:
+        raise AssertionError(f"rank {rank}: no LinAlgError for the indefinite Hessian")
     dist.barrier()
     dist.destroy_process_group()
     print(f"DIST_ROUND_OK rank {rank}", flush=True)

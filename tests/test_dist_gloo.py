@@ -42,7 +42,7 @@ class FakeBackend:
         self.factored.append(int(layer["id"]))
         order = torch.argsort(-layer["H"].diagonal().double(), stable=True)
         U = torch.triu(layer["H"].double() + layer["id"])
-        return order, U, torch.zeros(1, dtype=torch.int32)
+        return order, U, torch.full((1,), int(layer.get("bad", 0)), dtype=torch.int32)  # status word: 0 = positive definite
 
     def run_rows(self, layer, lo, hi, factor):
         order, U, _ = factor
@@ -138,6 +138,36 @@ def _worker_model_order(rank, size, port, q):
         be = FakeBatchBackend()
         shards = sdist.quantize_stream(layers, be)
         q.put((rank, be.rounds, be.factored, [(s["rows"], s["Q"].numpy().copy(), int(s["info"].item())) for s in shards]))
+    finally:
+        dist.destroy_process_group()
+
+
+class StatusBackend(FakeBatchBackend):
+    """+ the hook quantize_stream hands every layer's factorisation status to (HipBackend.note_statuses)."""
+
+    def __init__(self):
+        super().__init__()
+        self.statuses = None
+
+    def note_statuses(self, infos, layers, defer=False):
+        self.statuses = [None if i is None else int(i.item()) for i in infos]
+
+
+def make_layers_with_a_bad_one():
+    layers = make_equal_layers()
+    layers[3]["bad"] = 5  # its root (rank 1 of 2) reports a failing pivot: the word travels in the packed factor
+    layers[6]["bad"] = 2  # the lone last layer goes layer by layer (root: rank 0)
+    return layers
+
+
+def _worker_status(rank, size, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        be = StatusBackend()
+        sdist.quantize_stream(make_layers_with_a_bad_one(), be)
+        q.put((rank, be.statuses))
     finally:
         dist.destroy_process_group()
 
@@ -256,3 +286,23 @@ def test_model_order_stream_over_gloo_world2():
         (lo1, hi1), q1, i1 = got[1][3][l]
         assert (lo0, hi1) == (0, R) and hi0 == lo1 and i0 == 0 and i1 == 0
         assert torch.equal(torch.cat([torch.from_numpy(q0), torch.from_numpy(q1)]), single[l]["Q"])
+
+
+@pytest.mark.timeout(120)
+def test_factor_status_reaches_every_rank_over_gloo_world2():
+    """A factorisation that failed on its root (reference: LinAlgError, sleekit/obq.py:49-50) is reported for THAT layer on
+    every rank, through the batched-round route and the layer-by-layer one."""
+    be = StatusBackend()
+    sdist.quantize_stream(make_layers_with_a_bad_one(), be)
+    assert be.statuses == [0, 0, 0, 5, 0, 0, 2]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_status, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=90) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[0][1] == [0, 0, 0, 5, 0, 0, 2] and got[1][1] == [0, 0, 0, 5, 0, 0, 2]

@@ -131,3 +131,53 @@ def test_small_layers_in_batched_rounds_on_one_rank(moves):
         if b != 1:
             assert torch.equal(U[b], u1) and int(i1.item()) == 0
     assert int(info[1].item()) > 0
+
+
+def test_indefinite_hessian_in_a_batched_round_raises_naming_the_layer():
+    """One indefinite H among a round of 8 small layers (one rank: factored by slk_chol_inverse_upper_batch, looped as one
+    stack): quantize_stream raises numpy.linalg.LinAlgError like the reference's np.linalg.cholesky (sleekit/obq.py:49-50),
+    naming the layer; lazily (bench.py's mode, join=False) the same at raise_pending()."""
+    from sleekit_amd import _device as sdev
+    from sleekit_amd import codebook, synth
+    from sleekit_amd import dist as sdist
+
+    dev = torch.device("cuda", 0)
+    cb = codebook.UniformCodebook(8, -1, 1)
+    layers = []
+    for i in range(8):
+        L = synth.make_layer(128, 192, 3300 + i)
+        layers.append({k: torch.from_numpy(L[k]).to(dev) for k in ("W", "H", "scale")})
+    layers[5]["H"] = layers[5]["H"].clone()
+    layers[5]["H"][17, 17] = -1.0
+    be = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True)
+    calls = []
+    run_local = be.run_round_local
+    be.run_round_local = lambda members: (calls.append(len(members)), run_local(members))[1]
+    with pytest.raises(np.linalg.LinAlgError, match=r"layer 5 \(128 x 192\)"):
+        sdist.quantize_stream(layers, be)
+    assert calls == [8]  # one batched round
+    # wide layers (factor streams + loop stream route), the bad one second
+    wide = []
+    for i in range(3):
+        L = synth.make_layer(64, 1600, 3320 + i)
+        wide.append({k: torch.from_numpy(L[k]).to(dev) for k in ("W", "H", "scale")})
+    wide[1]["H"] = wide[1]["H"].clone()
+    wide[1]["H"][900, 900] = -2.0
+    be2 = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True)
+    be2.local_batch = 1  # layer by layer
+    with pytest.raises(np.linalg.LinAlgError, match=r"layer 1 \(64 x 1600\)"):
+        sdist.quantize_stream(wide, be2)
+    # deferred: nothing raised by the call, everything at raise_pending()
+    sdev.raise_pending()
+    try:
+        sdev.lazy_errors = True
+        sdist.quantize_stream(layers, be, join=False)
+        torch.cuda.synchronize()
+        with pytest.raises(np.linalg.LinAlgError, match=r"layer 5 "):
+            sdev.raise_pending()
+        sdist.quantize_stream([layers[i] for i in (0, 1, 2, 3)], be, join=False)
+        torch.cuda.synchronize()
+        sdev.raise_pending()  # a clean stream leaves nothing behind
+    finally:
+        sdev.lazy_errors = False
+        sdev._pending_info.clear()

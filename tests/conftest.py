@@ -40,6 +40,17 @@ def ls_traces():
 
 
 @pytest.fixture(scope="session")
+def orders():
+    return np.load(os.path.join(GOLDEN, "orders.npz"))
+
+
+@pytest.fixture(scope="session")
+def experiments():
+    with open(os.path.join(GOLDEN, "experiments.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
 def codebook_fit():
     return np.load(os.path.join(GOLDEN, "codebook_fit.npz"))
 

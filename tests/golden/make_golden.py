@@ -431,6 +431,63 @@ def codebook_fit():
     return out
 
 
+EXPERIMENT_LAYERS = (("a", 96, 172, 2003, ()), ("b", 64, 96, 2050, (5, 40)))  # name, rows, columns, seed, dead columns
+EXPERIMENT_RUNS = {  # script -> command-line arguments (small search grids: the fixtures pin call sequences, not runtimes)
+    "local_search": ["--codebook-size", "8", "--grid-size", "20"],
+    "correction": ["--codebook-size", "8", "--grid-size", "20"],
+    "ordering": ["--codebook-size", "8", "--grid-size", "20", "--correct-bias"],
+    "dampening": ["--codebook-size", "4", "--grid-size", "20"],
+    "bits": ["--grid-size", "16"],
+    "scaling": ["--codebook-size", "4", "--grid-size", "12", "--run-max", "--run-diag", "--run-diag1", "--run-diag3", "--run-diag10",
+                "--run-hessian", "--run-obq-aware"],
+    "compare": ["--codebook-size", "8", "--grid-size", "12"],
+}
+
+
+def write_experiment_data(root):
+    """The layer-statistics dumps the experiments walk (weight / hessian / mean .npy per directory, compare.py:37-53),
+    from the build's own generator.  tests/experiment_replays.py writes the same bytes on the GPU box."""
+    for name, R, n, seed, dead in EXPERIMENT_LAYERS:
+        L = synth.make_layer(R, n, seed, dead=dead) if dead else synth.make_layer(R, n, seed)
+        d = os.path.join(root, name)
+        os.makedirs(d, exist_ok=True)
+        np.save(os.path.join(d, "weight.npy"), L["W"])
+        np.save(os.path.join(d, "hessian.npy"), L["H"])
+        np.save(os.path.join(d, "mean.npy"), L["mean"])
+
+
+def experiments():
+    """Run the reference's OWN experiment scripts (experiments/*.py, unmodified, in a subprocess with the reference on the
+    path) on two synthetic layer dumps and keep the TSV they print: header + one row of layer errors per layer."""
+    import subprocess
+    import tempfile
+
+    out = dict(layers=[list(x[:4]) + [list(x[4])] for x in EXPERIMENT_LAYERS], runs={})
+    with tempfile.TemporaryDirectory() as tmp:
+        write_experiment_data(tmp)
+        for script, argv in EXPERIMENT_RUNS.items():
+            env = dict(os.environ, PYTHONPATH="/root/reference")
+            res = subprocess.run([sys.executable, f"/root/reference/experiments/{script}.py", tmp] + argv, env=env, capture_output=True,
+                                 text=True, check=True)
+            lines = [ln for ln in res.stdout.splitlines() if "\t" in ln]
+            out["runs"][script] = dict(argv=argv, header=lines[0].split("\t"), rows=[ln.split("\t") for ln in lines[1:]])
+            print(script, lines)
+    return out
+
+
+def inverse_diag_orders():
+    """obq.py:70-75: the orders that need diag(Hd^-1), and whole layers quantized in them."""
+    P = {}
+    for R_, n_, seed_ in ((64, 96, 2001), (96, 172, 2003)):
+        L = synth.make_layer(R_, n_, seed_)
+        Hd = L["H"] + 0.01 * L["H"].diagonal().mean() * np.eye(n_)
+        for mode in ("inv_diag", "combined_diag"):
+            P[f"{mode}/r{R_}_n{n_}_s{seed_}/order"] = ref_obq.compute_hessian_order(L["W"], Hd, UniformCodebook(8, -1, 1), mode).astype(np.int64)
+            P[f"{mode}/r{R_}_n{n_}_s{seed_}/out"] = ref_scaling.quantize_with_scaling(L["W"], L["scale"], UniformCodebook(8, -1, 1), H=L["H"],
+                                                                                     act_order=mode, damp=0.01)
+    return P
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true", help="also (re)generate large_cases.json (minutes)")
@@ -438,6 +495,8 @@ def main():
     ap.add_argument("--skip-small", action="store_true", help="leave small_cases.npz and pieces.npz as they are")
     ap.add_argument("--ls-traces", action="store_true", help="(re)generate ls_traces.npz (a minute: runs the large LS cases too)")
     ap.add_argument("--codebook-fit", action="store_true", help="(re)generate codebook_fit.npz (seconds)")
+    ap.add_argument("--experiments", action="store_true", help="(re)generate experiments.json: the reference's experiment scripts' TSV (a minute)")
+    ap.add_argument("--orders", action="store_true", help="(re)generate orders.npz: inv_diag / combined_diag (seconds)")
     args = ap.parse_args()
 
     env = dict(numpy=np.__version__, python=sys.version.split()[0], cpu_count=os.cpu_count())
@@ -451,6 +510,11 @@ def main():
         np.savez_compressed(os.path.join(HERE, "pieces.npz"), **pieces())
         with open(os.path.join(HERE, "environment.json"), "w") as f:
             json.dump(env, f, indent=1)
+    if args.experiments:
+        with open(os.path.join(HERE, "experiments.json"), "w") as f:
+            json.dump(dict(environment=env, **experiments()), f, indent=1)
+    if args.orders:
+        np.savez_compressed(os.path.join(HERE, "orders.npz"), **inverse_diag_orders())
     if args.codebook_fit:
         np.savez_compressed(os.path.join(HERE, "codebook_fit.npz"), **codebook_fit())
     if args.ls_traces:

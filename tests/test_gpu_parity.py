@@ -7,6 +7,7 @@ need not match LAPACK bit-wise: SURVEY.md 8a6); layer errors to 1e-5 relative (n
 
 import hashlib
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -408,8 +409,9 @@ def test_quantize_opt_direct_and_device_tensors(amd):
 
 
 @pytest.mark.parametrize("order", ["inv_diag", "combined_diag"])
-def test_orders_from_the_inverse_diagonal(amd, order):
-    """obq.py:70-75: orders that need diag(Hd^-1); here from a first factorisation in the original order."""
+def test_orders_from_the_inverse_diagonal(amd, order, orders):
+    """obq.py:70-75: orders that need diag(Hd^-1); here from a first factorisation in the original order.  Against the
+    REFERENCE's order and output (tests/golden/orders.npz) and the oracle's."""
     for R, n, seed in ((64, 96, 2001), (96, 172, 2003)):
         L = layer(R, n, seed)
         g = grid.UniformGrid(8, -1, 1)
@@ -417,6 +419,29 @@ def test_orders_from_the_inverse_diagonal(amd, order):
         want = scaling_ref.quantize_scaled(L["W"], L["scale"], g, L["H"], order, 0.01, 0)
         got = amd.scaling.quantize_with_scaling(L["W"], L["scale"], cb, L["H"], act_order=order, damp=0.01)
         assert np.array_equal(got, want), (order, n)
+        tag = f"{order}/r{R}_n{n}_s{seed}"
+        assert np.array_equal(got, orders[tag + "/out"]), tag
+
+
+def test_experiment_scripts_replayed_over_the_dropin_package(experiments, tmp_path):
+    """north_star: "drops in under experiments/*.py".  The scripts do `from sleekit.codebook import *` (+ .obq, .scaling;
+    experiments/compare.py:1-3) and use `np` without importing it.  With dropin/ on the path those lines resolve to this
+    build; the main loops of local_search / correction / ordering / dampening / bits / scaling / compare
+    (tests/experiment_replays.py) over the star-imported names must print the layer errors the reference's own scripts
+    printed for the same dumps (tests/golden/experiments.json)."""
+    import experiment_replays
+
+    dropin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropin")
+    sys.path.insert(0, dropin)
+    try:
+        ns = {}
+        exec("from sleekit.codebook import *\nfrom sleekit.obq import *\nfrom sleekit.scaling import *\n", ns)
+        import sleekit
+
+        assert sleekit.__file__.startswith(dropin) and ns["UniformCodebook"].__module__ == "sleekit_amd.codebook"
+        experiment_replays.check_against_fixture(experiments, ns, str(tmp_path))
+    finally:
+        sys.path.remove(dropin)
 
 
 @pytest.mark.parametrize("staged", [False, True])

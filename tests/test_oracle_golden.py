@@ -155,23 +155,42 @@ def test_gains(pieces):
     assert np.array_equal(obq_ref.flip_gains(Ws, Q0, L["H"], g.down(Q0)), pieces["gain/down"])
 
 
-def test_inverse_diagonal_orders_match_reference():
-    """The two orders added after the golden fixtures were cut: checked against the reference directly
-    when it is mounted (build container), skipped elsewhere."""
-    import os
-    import sys
+def test_inverse_diagonal_orders_match_reference(orders):
+    """obq.py:70-75, inv_diag / combined_diag: the reference's orders and the layers it quantized in them
+    (tests/golden/orders.npz, made by make_golden.py --orders from the imported reference)."""
+    g = grid.UniformGrid(8, -1, 1)
+    for R, n, seed in ((64, 96, 2001), (96, 172, 2003)):
+        L = layer(R, n, seed)
+        Hd = L["H"] + 0.01 * L["H"].diagonal().mean() * np.eye(n)
+        for mode in ("inv_diag", "combined_diag"):
+            tag = f"{mode}/r{R}_n{n}_s{seed}"
+            assert np.array_equal(obq_ref.column_order(L["W"], Hd, None, mode), orders[tag + "/order"]), tag
+            got = scaling_ref.quantize_scaled(L["W"], L["scale"], g, L["H"], mode, 0.01, 0)
+            assert np.array_equal(got, orders[tag + "/out"]), tag
 
-    if not os.path.isdir("/root/reference/sleekit"):
-        pytest.skip("reference not mounted")
-    sys.path.insert(0, "/root/reference")
-    from sleekit import obq as ref_obq
-    from sleekit.codebook import UniformCodebook
 
-    L = layer(64, 96, 2001)
-    Hd = L["H"] + 0.01 * L["H"].diagonal().mean() * np.eye(96)
-    for mode in ("inv_diag", "combined_diag"):
-        want = ref_obq.compute_hessian_order(L["W"], Hd, UniformCodebook(8, -1, 1), mode)
-        assert np.array_equal(obq_ref.column_order(L["W"], Hd, None, mode), want)
+def oracle_namespace():
+    """The oracle under the reference's names: what `from sleekit.codebook / obq / scaling import *` gives an experiment."""
+    return dict(
+        np=np, UniformCodebook=grid.UniformGrid, remove_dead_values=obq_ref.patch_dead_columns, remove_input_bias=obq_ref.strip_input_mean,
+        quantization_error=lambda W, Q, H: obq_ref.mean_error(W, Q, H),
+        compute_scaling=lambda W, cb, H, mode="mse", axis=0, min_factor=0.05, max_factor=1.0, grid_size=100:
+        scaling_ref.pick_scale(W, cb, H, mode=mode, axis=axis, min_factor=min_factor, max_factor=max_factor, grid_size=grid_size),
+        compute_min_mse_scaling=scaling_ref.best_grid_scale,
+        compute_obq_scaling=lambda W, cb, axis, H, damp=0.01, act_order="diag", min_factor=0.05, max_factor=1.0, grid_size=100:
+        scaling_ref.best_obq_scale(W, cb, axis, H, damp=damp, order_mode=act_order, min_factor=min_factor, max_factor=max_factor, grid_size=grid_size),
+        quantize_with_scaling=lambda W, sc, cb, H=None, act_order="diag", damp=0.01, nb_ls_moves=0:
+        scaling_ref.quantize_scaled(W, sc, cb, H, act_order, damp, nb_ls_moves),
+    )
+
+
+def test_experiment_scripts_replayed_over_the_oracle(experiments, tmp_path):
+    """The call sequences of the reference's experiment scripts (tests/experiment_replays.py) over the oracle give the layer
+    errors the scripts themselves printed (tests/golden/experiments.json): exactly -- the oracle IS the reference's
+    arithmetic on the same BLAS -- so every column is held to 1e-5, the choice-ranked ones too."""
+    import experiment_replays
+
+    experiment_replays.check_against_fixture(experiments, oracle_namespace(), str(tmp_path), loose_rtol=1e-5)
 
 
 def test_table_codebook_matches_reference(pieces):

@@ -61,18 +61,19 @@ extern "C" {
 typedef void *slk_stream_t;
 
 /* Library / device ---------------------------------------------------------
- * slk_abi_version: 5.  History: 2 = every quantizing entry takes (levels, lo, hi, table); 3 adds the batch forms
+ * slk_abi_version: 6.  History: 2 = every quantizing entry takes (levels, lo, hi, table); 3 adds the batch forms
  * (slk_gptq_quantize_batch, slk_row_errors_batch, slk_workspace_bytes_batch) and slk_symmetry_flag; 4 adds the
  * `trace` and `gains` arguments of slk_local_search, slk_set_option / slk_get_option and the batched factorisation
  * (slk_hessian_prepare_batch, slk_chol_inverse_upper_batch, slk_factor_workspace_bytes_batch); 5 adds codebook training
- * (slk_codebook_stats, slk_sort_f32, slk_unique_f32), slk_local_search_batch and slk_factor_unpack_upper_batch.                                                          */
+ * (slk_codebook_stats, slk_sort_f32, slk_unique_f32), slk_local_search_batch and slk_factor_unpack_upper_batch; 6 adds
+ * slk_chol_inverse_upper_lookahead and slk_release_helpers (the look-ahead is an argument of the call, not a process-wide switch).                                                          */
 int slk_abi_version(void);
 const char *slk_last_error(void);
 /* Run-time switches between code paths that give the same results (the tests hold them to that) or that shape a
  * measurement: "no_window2", "no_fast_leaf", "no_defer", "win_dbg", "no_regular_search", "no_fast_search_div",
  * "no_error_splitk", "error_cb", "no_sym_error", "no_bf16_error", "no_bf16_dma", "no_bf16_hessian", "no_bf16_asym", "no_sym_average",
- * "error_f32_below", "no_wave_search", "lookahead" (a factorisation forks the bulk of its outer updates onto a helper stream: for one layer
- * at a time; sleekit_amd.engine.quantize_layer sets it around its own factorisation), "window_rows" (16 or 32 rows per
+ * "error_f32_below", "no_wave_search", "lookahead" (EVERY factorisation forks the bulk of its outer updates onto a helper stream: a measurement
+ * switch; one call at a time asks for it through slk_chol_inverse_upper_lookahead instead), "window_rows" (16 or 32 rows per
  * window workgroup; 0 = 16) (case-insensitive,
  * an "SLK_" prefix is accepted).  Initial values are read ONCE from the environment (SLK_NO_WINDOW2=1 ...);
  * afterwards only these calls change them.  Process-wide, thread-safe; no reference counterpart.              */
@@ -171,6 +172,15 @@ int slk_factor_load(const double *M, int n, double *A, slk_stream_t stream);
  *     pivot appeared -- the reference raises numpy.linalg.LinAlgError there.    */
 int slk_chol_inverse_upper(double *A, int n, double *U, int *info, void *workspace,
                            size_t ws_bytes, slk_stream_t stream);
+/*     The same with LOOK-AHEAD: after a block's panels only the next block's tile columns are updated on `stream`, the
+ *     rest of the trailing triangle runs on a helper stream beside the next block's panels (forked and joined by events
+ *     inside the call: the caller still sees one stream).  Same updates per tile in the same order: U bit for bit.  For
+ *     ONE layer at a time (latency); with several factorisations in flight on streams of their own the plain form is
+ *     faster.  The helper stream and its events are made at first use per (device, stream) and live until
+ *     slk_release_helpers(), which waits for the helpers and destroys them (call it before destroying such a stream).   */
+int slk_chol_inverse_upper_lookahead(double *A, int n, double *U, int *info, void *workspace,
+                                     size_t ws_bytes, slk_stream_t stream);
+int slk_release_helpers(void);
 
 /* (a3-a6 for `batch` layers of ONE width n at once: every launch covers all the layers -- blockIdx.z is the layer --
  * so a round of small layers costs the launches of one.  Small layers are bound by the host's launch rate, not by the
@@ -254,7 +264,10 @@ int slk_symmetry_flag(const float *H, int n, int *flag, slk_stream_t stream);
  *     pairwise order, so that from equal initial gains the moves are the reference's bit for bit.
  *     trace (may be NULL): R x moves int32, the moves taken -- 2 * column + (1: up, 0: down), or -1 from
  *     the first move on at which the row had nothing left to gain (parity tests compare it with the
- *     reference's sequence of moves to find where, if anywhere, a near-tie fell the other way).
+ *     reference's sequence of moves to find where, if anywhere, a near-tie fell the other way).  A "move" onto the
+ *     value a weight already holds changes nothing and the reference repeats it until its moves run out: the search
+ *     of that row ends there and the trace carries the repeats, as the reference's own record does.  (The carried
+ *     gains of gains_mode 1 / 2 then lack the reference's additions of +0.0: at most the sign of a zero differs.)
  *     gains / gains_mode: the state of the reference's stateful LocalSearchQuantizer (obq.py:234-346) between calls --
  *     R x 2 x n float32, per row the n up-gains then the n down-gains.  gains_mode 0: none (gains may be NULL);
  *     1: the initial gains are built from (W - Q) H as usual, and the gains after the moves are stored (moves == 0

@@ -84,7 +84,9 @@ def scratch(nbytes, tag="scratch"):
 
 
 def release_workspaces():
+    """Drop the scratch tensors and the library's helper streams / events (waits for the helpers first)."""
     _workspaces.clear()
+    _lib.check(_lib.lib.slk_release_helpers())
 
 
 def note_info(info, what, defer=False):

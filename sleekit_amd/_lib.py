@@ -51,6 +51,8 @@ PROTOTYPES = {
     "slk_factor_ld": (c_int, [c_int]),
     "slk_factor_load": (c_int, [P, c_int, P, P]),
     "slk_chol_inverse_upper": (c_int, [P, c_int, P, P, P, c_size_t, P]),
+    "slk_chol_inverse_upper_lookahead": (c_int, [P, c_int, P, P, P, c_size_t, P]),
+    "slk_release_helpers": (c_int, []),
     "slk_hessian_prepare_batch": (c_int, [P, c_int, c_int, c_float, c_int, P, P, P, c_size_t, P]),
     "slk_chol_inverse_upper_batch": (c_int, [P, c_int, c_int, P, P, P, c_size_t, P]),
     "slk_factor_workspace_bytes_batch": (c_size_t, [c_int, c_int]),

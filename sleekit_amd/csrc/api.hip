@@ -213,28 +213,60 @@ int opt(Opt o) {
 
 namespace {
 std::mutex g_helper_mu;
-std::map<std::pair<int, hipStream_t>, Helper> g_helpers;
+struct HelperRec {
+    Helper h;
+    int made;  // events created so far
+};
+std::map<std::pair<int, hipStream_t>, HelperRec> g_helpers;
 }  // namespace
 
-hipError_t helper_for(hipStream_t main, Helper *out) {
+hipError_t helper_for(hipStream_t main, int need, Helper *out) {
+    if (need > HELPER_EVENTS) return hipErrorInvalidValue;
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(g_helper_mu);
     auto it = g_helpers.find({device, main});
     if (it == g_helpers.end()) {
-        Helper h;
-        e = hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking);
+        HelperRec r{};
+        e = hipStreamCreateWithFlags(&r.h.stream, hipStreamNonBlocking);
         if (e != hipSuccess) return e;
-        h.events = new hipEvent_t[HELPER_EVENTS];
-        for (int i = 0; i < HELPER_EVENTS; ++i) {
-            e = hipEventCreateWithFlags(&h.events[i], hipEventDisableTiming);
-            if (e != hipSuccess) return e;
-        }
-        it = g_helpers.emplace(std::make_pair(device, main), h).first;
+        r.h.events = new hipEvent_t[HELPER_EVENTS]();
+        r.made = 0;
+        it = g_helpers.emplace(std::make_pair(device, main), r).first;
     }
-    *out = it->second;
+    HelperRec &r = it->second;
+    const int had = r.made;
+    while (r.made < need) {
+        e = hipEventCreateWithFlags(&r.h.events[r.made], hipEventDisableTiming);
+        if (e != hipSuccess) {  // give back what this call made; what earlier calls made stays usable
+            while (r.made > had) (void)hipEventDestroy(r.h.events[--r.made]);
+            if (had == 0) {
+                (void)hipStreamDestroy(r.h.stream);
+                delete[] r.h.events;
+                g_helpers.erase(it);
+            }
+            return e;
+        }
+        ++r.made;
+    }
+    *out = r.h;
     return hipSuccess;
+}
+
+static hipError_t release_helpers() {
+    std::lock_guard<std::mutex> lock(g_helper_mu);
+    hipError_t first = hipSuccess;
+    for (auto &kv : g_helpers) {
+        HelperRec &r = kv.second;
+        hipError_t e = hipStreamSynchronize(r.h.stream);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+        for (int i = 0; i < r.made; ++i) (void)hipEventDestroy(r.h.events[i]);
+        (void)hipStreamDestroy(r.h.stream);
+        delete[] r.h.events;
+    }
+    g_helpers.clear();
+    return first;
 }
 
 hipError_t lds_opt_in(const void *kernel, size_t bytes) {
@@ -251,6 +283,10 @@ hipError_t lds_opt_in(const void *kernel, size_t bytes) {
 }  // namespace slk
 
 extern "C" {
+int slk_release_helpers(void) {
+    SLK_HIP(slk::release_helpers());
+    return SLK_OK;
+}
 int slk_set_option(const char *name, int value) {
     const int i = opt_index(name);
     SLK_REQUIRE(i >= 0, "unknown option %s", name ? name : "(null)");

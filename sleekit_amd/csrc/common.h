@@ -93,10 +93,12 @@ int opt(Opt o);
 // one stream.  Fork and join are event record / wait pairs, which a hipGraph capture of the caller's stream follows.
 struct Helper {
     hipStream_t stream;
-    hipEvent_t *events;  // HELPER_EVENTS of them
+    hipEvent_t *events;  // room for HELPER_EVENTS; the first `need` of helper_for exist
 };
 constexpr int HELPER_EVENTS = 512;
-hipError_t helper_for(hipStream_t main, Helper *out);
+// the helper of (current device, main) with at least `need` events (created as they are first asked for; on failure
+// nothing made by the call is kept).  slk_release_helpers() destroys them all.
+hipError_t helper_for(hipStream_t main, int need, Helper *out);
 
 // Opt a kernel in to `bytes` of dynamic LDS (above the 64 KB default) on the CURRENT device; remembered per
 // (kernel, device), safe to call from several threads.  Returns a hipError_t.

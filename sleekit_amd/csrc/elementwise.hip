@@ -152,7 +152,7 @@ using namespace slk;
 
 extern "C" {
 
-int slk_abi_version(void) { return 5; }
+int slk_abi_version(void) { return 6; }
 
 const char *slk_last_error(void) { return g_error; }
 

@@ -364,7 +364,7 @@ __global__ void k_clear_info(int *info) { info[blockIdx.x] = 0; }
 using namespace slk;
 
 static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, void *workspace, size_t ws_bytes,
-                             slk_stream_t stream) {
+                             slk_stream_t stream, bool want_lookahead) {
     const int ld = slk_factor_ld(n);
     const int nt = ld / TILE;
     const unsigned B = (unsigned)batch;
@@ -386,8 +386,8 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
     // (4850 -> 3560 Mweights/s on one rank whatever GPU_MAX_HW_QUEUES is, 4.7 -> 7.3 ms per step of a rank of 8).  So it
     // is a switch, off by default, which the single-layer API turns on (sleekit_amd/engine.py: quantize_layer).
     Helper helper{};
-    const bool lookahead = opt(OPT_LOOKAHEAD) && nt >= LOOKAHEAD_MIN_TILES + OUTER / TILE && nt / (OUTER / TILE) < HELPER_EVENTS / 2;
-    if (lookahead) SLK_HIP(helper_for(s, &helper));
+    const bool lookahead = (want_lookahead || opt(OPT_LOOKAHEAD)) && nt >= LOOKAHEAD_MIN_TILES + OUTER / TILE && nt / (OUTER / TILE) < HELPER_EVENTS / 2;
+    if (lookahead) SLK_HIP(helper_for(s, 2 * (nt / (OUTER / TILE) + 1), &helper));  // two events per outer block
     int block = 0, forked = -1;  // forked: the last block whose rest went to the helper and has not been joined
     for (int K0 = 0; K0 < ld; K0 += OUTER) {
         const int K1 = K0 + OUTER < ld ? K0 + OUTER : ld;
@@ -466,14 +466,20 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
 extern "C" int slk_chol_inverse_upper(double *A, int n, double *U, int *info, void *workspace,
                                       size_t ws_bytes, slk_stream_t stream) {
     SLK_REQUIRE(A && U && info && n > 0, "bad arguments");
-    return chol_inverse_impl(A, 1, n, U, info, workspace, ws_bytes, stream);
+    return chol_inverse_impl(A, 1, n, U, info, workspace, ws_bytes, stream, false);
+}
+
+extern "C" int slk_chol_inverse_upper_lookahead(double *A, int n, double *U, int *info, void *workspace,
+                                                size_t ws_bytes, slk_stream_t stream) {
+    SLK_REQUIRE(A && U && info && n > 0, "bad arguments");
+    return chol_inverse_impl(A, 1, n, U, info, workspace, ws_bytes, stream, true);
 }
 
 extern "C" int slk_chol_inverse_upper_batch(double *A, int batch, int n, double *U, int *info, void *workspace,
                                             size_t ws_bytes, slk_stream_t stream) {
     SLK_REQUIRE(A && U && info && n > 0, "bad arguments");
     SLK_REQUIRE(batch >= 1 && batch <= 64, "batch must be 1..64");
-    return chol_inverse_impl(A, batch, n, U, info, workspace, ws_bytes, stream);
+    return chol_inverse_impl(A, batch, n, U, info, workspace, ws_bytes, stream, false);
 }
 
 extern "C" size_t slk_factor_workspace_bytes_batch(int batch, int n) {

@@ -82,11 +82,8 @@ class LayerResult:
 def factorize(H, n, damp, mode, miss=None, keep=None, lookahead=False):
     """Damping + order + float64 factor for a float32 device Hessian. Returns (order, U, info).
     lookahead: one layer at a time (latency matters, nothing else is in flight): the factorisation forks the bulk of
-    its outer updates onto a helper stream (slk_set_option "lookahead"; off for the multi-stream pipelines of
-    sleekit_amd.dist, where the extra streams cost more than they save)."""
-    if lookahead:
-        with _lib.option("lookahead", 1):
-            return factorize(H, n, damp, mode, miss, keep)
+    its outer updates onto a helper stream (slk_chol_inverse_upper_lookahead: an argument of THIS call, no process-wide
+    switch; off for the multi-stream pipelines of sleekit_amd.dist, where the extra streams cost more than they save)."""
     ws, ws_bytes = dev.workspace(0, n)
     s = dev.stream_handle()
     ld = _lib.lib.slk_factor_ld(n)
@@ -99,7 +96,8 @@ def factorize(H, n, damp, mode, miss=None, keep=None, lookahead=False):
             dev.ptr(H), n, float(damp), mode, dev.ptr(miss), dev.ptr(order), dev.ptr(A), dev.ptr(ws), ws_bytes, s
         )
     )
-    _lib.check(_lib.lib.slk_chol_inverse_upper(dev.ptr(A), n, dev.ptr(U), dev.ptr(info), dev.ptr(ws), ws_bytes, s))
+    chol = _lib.lib.slk_chol_inverse_upper_lookahead if lookahead else _lib.lib.slk_chol_inverse_upper
+    _lib.check(chol(dev.ptr(A), n, dev.ptr(U), dev.ptr(info), dev.ptr(ws), ws_bytes, s))
     return order, U, info
 
 

@@ -138,8 +138,13 @@ def _search_stacked(W, base, factors, H, quantize_rows):
     for c0 in range(0, len(factors), per):
         f = fac[c0:c0 + per]
         G = f.numel()
+        if G < per and c0 > 0:
+            # a short last chunk is padded to the size of the others (its last point repeated, results unused): the layer
+            # error picks its K split from the stack's tile count, and every grid point of a row must be summed in the
+            # same order for the first-best `<` below to rank like errors
+            f = torch.cat([f, f[-1:].expand(per - G)])
         scales = (f[:, None] * base[None, :]).reshape(-1)  # float32 products, like `s * initial_scale`
-        Wst = W.unsqueeze(0).expand(G, R, n).reshape(G * R, n)
+        Wst = W.unsqueeze(0).expand(f.numel(), R, n).reshape(f.numel() * R, n)
         err = engine.row_errors(quantize_rows(Wst, scales), Wst, H)
         for g in range(G):
             _lib.check(_lib.lib.slk_search_step(err[g * R:(g + 1) * R].data_ptr(), float(factors[c0 + g]), R, dev.ptr(best_err),

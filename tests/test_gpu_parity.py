@@ -252,8 +252,15 @@ def test_factor_lookahead_changes_nothing(amd):
     o0, U0, i0 = amd.engine.factorize(L["H"], n, 0.01, amd.lib.ORDER_DIAG)
     o1, U1, i1 = amd.engine.factorize(L["H"], n, 0.01, amd.lib.ORDER_DIAG, lookahead=True)
     torch.cuda.synchronize()
-    assert amd.lib.lib.slk_get_option(b"lookahead") == 0  # (restored)
+    assert amd.lib.lib.slk_get_option(b"lookahead") == 0  # (an argument of the call: no process-wide switch is touched)
     assert torch.equal(o0, o1) and torch.equal(U0, U1) and int(i0.item()) == int(i1.item()) == 0
+    # the helper stream and its events go when asked to, and come back at the next use
+    from sleekit_amd import _device as sdev
+
+    sdev.release_workspaces()
+    o2, U2, i2 = amd.engine.factorize(L["H"], n, 0.01, amd.lib.ORDER_DIAG, lookahead=True)
+    torch.cuda.synchronize()
+    assert torch.equal(U0, U2)
 
 
 def test_factor_of_plain_matrix_and_not_pd(amd):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mweights/s quantized (GPTQ 3-bit, 4096 x 4096 layers) on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5]
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--no-configs]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One STEP = one pass of the hot path over a batch of synthetic layers, every layer with inputs of its own:
@@ -19,7 +19,9 @@ with W, H and the row scales resident in HBM before the clock starts.  N > 1 sha
 rows of every layer across the ranks (sleekit_amd/dist.py); the factors are made by the ranks in turn and cross
 xGMI once, in one RCCL all-gather per round of N same-shaped layers.  Total work is the same at every N ("strong").
 
-The JSON line also carries
+The ONE JSON line carries the headline run and, unless --no-configs / --config is given, every other BASELINE config
+as a short leg of its own under "configs" (cfg2, cfg3, cfg4: 3 steps; cfg5: 2 steps of 16 of its 32 layers), each with its
+own roofline and CPU baseline, so that one driver run backs every number of DESIGN.md's table.  Fields besides the contract's:
   roofline      for the kernel with the largest share of the chip's time IN THE TIMED CONFIGURATION (HIP events
                  around every launch, on the launch stream: slk_profile_* in the C ABI; a launch of fewer than 256
                  workgroups counts for that share of its duration); achieved = ALGORITHMIC flops or bytes of its
@@ -28,17 +30,22 @@ The JSON line also carries
                  `loop` = the whole error-update loop (window + trailing kernels: SURVEY.md 8 a8 + a9) priced as one
                  thing, alone and as timed;
   latency_ms_single_layer   one isolated layer, start to finish (SURVEY.md 8e);
-  asymmetric_H  the same workload with Hessians made by torch `X.T @ X` (not bit-symmetric, like the experiments' dumps):
-                 the layer error then averages H with its transpose on the way into its operand planes to keep
-                 the half-product route;
-  cpu_baseline  the NumPy oracle (bit-identical to the reference, tests/test_oracle_golden.py)
-                 timed on this host for one layer of the workload, rank 0, N = 1 only.
+  asymmetric_H  the same workload with Hessians that are not bit-symmetric (like the experiments' dumps);
+  cpu_baseline  the NumPy oracle (bit-identical to the reference, tests/test_oracle_golden.py) timed on this host, rank 0,
+                 N = 1 only: headline = one layer, best of 3 after a warm-up; configs = one layer per distinct shape,
+                 weighted by the shape's count in the model;
+  layer_errors  the layer error of EVERY layer of the last timed step (all finite), and where the CPU ran the same layer,
+                 the relative difference to the oracle's error;
+  rccl          (N > 1) what the collective did: world size, backend, bytes a rank receives per step, the exchange's
+                 duration measured by events on the comm stream, and whether every rank's copy of the payloads carried its
+                 root's checksum (sleekit_amd.dist.verify_exchange).
 """
 
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -62,9 +69,11 @@ import torch.distributed as dist
 PEAK = {"hbm": (8.0e12, "GB/s"), "mfma_f64": (78.6e12, "TFLOP/s"), "mfma_f32": (157.3e12, "TFLOP/s"), "mfma_bf16": (2.5e15, "TFLOP/s")}
 KERNEL_DTYPE = {
     "chol_panel": "mfma_f64", "chol_syrk_inner": "mfma_f64", "chol_syrk_outer": "mfma_f64", "trtri_stage0": "mfma_f64", "trtri_stage1": "mfma_f64",
+    "chol_syrk_ahead": "mfma_f64", "trtri_level": "mfma_f64", "chol_block": "mfma_f64",
     "gptq_window": "mfma_f64", "gptq_window_wide": "mfma_f64", "gptq_trailing": "mfma_f64",
     "error_gemm": "mfma_f32", "error_gemm_bf16": "mfma_bf16", "hessian_syrk": "mfma_f32",
 }
+LOOP_KERNELS = ("gptq_window", "gptq_window_wide", "gptq_trailing")
 
 # BASELINE.json configs as layer streams in model order (shapes from results/compare_3b.csv's layer names)
 WORKLOADS = {
@@ -75,6 +84,8 @@ WORKLOADS = {
                  moves=10, strip=False),
     "cfg5": dict(name="Llama-FFN 4096x11008 x 32", block=[(4096, 11008)], blocks=32, levels=4, moves=0, strip=False),
 }
+# the short legs of the default run: (steps, warm-up, blocks of the model; 0 = all)
+CONFIG_LEGS = {"cfg2": (3, 1, 0), "cfg3": (3, 1, 0), "cfg4": (3, 1, 0), "cfg5": (2, 1, 16)}
 
 
 def parse():
@@ -93,209 +104,189 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-layer latency, asymmetric-H and Hessian-accumulation legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configs (cfg2 ... cfg5)")
+    ap.add_argument("--configs", type=str, default="", help="comma-separated subset of the config legs (default: all four)")
     ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts (default 3,1)")
     ap.add_argument("--stages", action="store_true", help="also print per-kernel timing table to stderr")
-    ap.add_argument("--graphs", action="store_true",
-                    help="replay each layer's pipeline from a hipGraph (one launch per layer): for small, launch-bound layers; N = 1")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.config:
-        wl = dict(WORKLOADS[args.config])
-        if args.blocks:
-            wl["blocks"] = args.blocks
-        shapes = wl["block"] * wl["blocks"]
-        levels, moves, strip = wl["levels"], wl["moves"], wl["strip"]
-    else:
-        shapes = [(args.rows, args.cols)] * args.layers
-        levels, moves, strip = args.levels, args.moves, False
-    L = len(shapes)
-    widest = max(n for _, n in shapes)
-    launch_bound = widest <= 1024 and world == 1  # small shapes (see the note on hardware queues at the top)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if launch_bound else "8")
-    assert torch.cuda.is_available(), "bench.py needs the MI355X"
-    dev_index = local_rank % torch.cuda.device_count()  # (a rehearsal may put several ranks on one GPU)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend_name = os.environ.get("SLK_DIST_BACKEND", "nccl")  # "gloo" only to rehearse on a 1-GPU box
-        if backend_name == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend_name)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+class Env:
+    """What every leg shares: the process group, the device, the library."""
 
-    from sleekit_amd import _device as dev
-    from sleekit_amd import _lib, codebook, synth
-    from sleekit_amd import dist as sdist
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    dev.lazy_errors = True
-    cb = codebook.UniformCodebook(levels, -1, 1)
+    def start(self, launch_bound):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if launch_bound else "8")
+        assert torch.cuda.is_available(), "bench.py needs the MI355X"
+        dev_index = self.local_rank % torch.cuda.device_count()  # (a rehearsal may put several ranks on one GPU)
+        torch.cuda.set_device(dev_index)
+        self.device = torch.device("cuda", dev_index)
+        self.backend_name = "none"
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            self.backend_name = os.environ.get("SLK_DIST_BACKEND", "nccl")  # "gloo" only to rehearse on a 1-GPU box
+            if self.backend_name == "nccl":
+                dist.init_process_group("nccl", device_id=self.device)
+            else:
+                dist.init_process_group(self.backend_name)
+        assert self.world == self.args.gpus, f"--gpus {self.args.gpus} but WORLD_SIZE={self.world}"
 
-    # ---- inputs, resident in HBM (identical on every rank: integer-hash generator, run on the GPU -- same bytes as
-    #      synth.make_layer on the host, tests/test_gpu_parity.py::test_device_generator_makes_the_same_bytes)
-    t_setup = time.time()
-    distinct = args.distinct if args.distinct > 0 else L
-    made = {}
-    layers = []
-    for i, (R, n) in enumerate(shapes):
-        key = (R, n, i % distinct)
-        if key not in made:
-            lay = synth.make_layer_device(R, n, 1000 + i, device)
-            made[key] = {k: lay[k] for k in ("W", "H", "scale", "mean")}
-        layers.append(made[key])
-    torch.cuda.synchronize()
-    host_layer0 = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        R0, n0 = shapes[0]
-        rows0 = min(R0, 512) if n0 > 8192 else R0  # (the n^3 factorisation of an 11008-column layer alone is most of a minute)
-        host_layer0 = {k: layers[0][k][:rows0].cpu().numpy() if k != "H" else layers[0][k].cpu().numpy() for k in ("W", "H", "scale", "mean")}
-    t_setup = time.time() - t_setup
-    weights_per_step = float(sum(R * n for R, n in shapes))
-
-    # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: one loop stream; the batched rounds run on the factor streams)
-    # (from 4 ranks up a rank factors one or two layers per step: TWO factor streams and the batched rounds on a loop
-    # stream of their own measured best -- one rank's step of the headline batch, tools/micro_rank_of_n.py with
-    # ROUNDS_ON_FS / NF / NL: N = 8: 4.3 ms against 4.7 with the rounds on the factor streams and 5.1 ... 5.4 with three
-    # factor streams; N = 4: 7.9 against 8.5 ... 9.8; N = 2 keeps three factor streams and rounds on them, 14.8 against 15.4)
-    few_factors = world >= 4
-    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else ((3, 3) if launch_bound else ((2, 1) if few_factors else (3, 1)))
-    backend = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=streams)
-    if few_factors:
-        backend.rounds_on_factor_streams = False
-
-    in_flight = []  # per enqueued step: events at the tail of its loop streams
-
-    graphed, gstreams = [], []
-    if args.graphs:
-        assert world == 1 and not strip, "--graphs is a single-GPU mode"
-        from sleekit_amd import graphs
-
-        gstreams = [torch.cuda.Stream() for _ in range(sum(streams))]
-        for i, lay in enumerate(layers):
-            # the inputs are resident: the graph reads them in place
-            R, n = shapes[i]
-            g = graphs.GraphedLayer(R, n, cb, "diag", 0.01, with_error=True, device=device, inputs=(lay["W"], lay["H"], lay["scale"]))
-            with torch.cuda.stream(gstreams[i % len(gstreams)]):
-                g.capture()
-            graphed.append(g)
+    def fence(self):
+        if self.world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
 
-    def step_graphs():
-        here = torch.cuda.current_stream()
-        for st in gstreams:
-            st.wait_stream(here)
-        for i, g in enumerate(graphed):
-            with torch.cuda.stream(gstreams[i % len(gstreams)]):
-                g()
-        evs = []
-        for st in gstreams:
-            e = torch.cuda.Event()
-            e.record(st)
-            evs.append(e)
-        in_flight.append(evs)
-        if len(in_flight) > 4:
-            for e in in_flight.pop(0):
-                e.synchronize()
-        return [dict(row_err=g.row_err) for g in graphed]
 
-    def strip_mean(lay):
+class Leg:
+    """One workload on this process group: inputs, backend, the timed loop and its measurements."""
+
+    def __init__(self, env, tag, shapes, levels, moves, strip, streams=None, distinct=0):
+        from sleekit_amd import codebook, synth
+        from sleekit_amd import dist as sdist
+
+        self.env, self.tag, self.shapes, self.levels, self.moves, self.strip = env, tag, shapes, levels, moves, strip
+        self.L = len(shapes)
+        self.widest = max(n for _, n in shapes)
+        self.cb = codebook.UniformCodebook(levels, -1, 1)
+        self.weights_per_step = float(sum(R * n for R, n in shapes))
+        world = env.world
+        # ---- inputs, resident in HBM (identical on every rank: integer-hash generator, run on the GPU -- same bytes as
+        #      synth.make_layer on the host, tests/test_gpu_parity.py::test_device_generator_makes_the_same_bytes)
+        t0 = time.time()
+        distinct = distinct if distinct > 0 else self.L
+        self.made, self.layers = {}, []
+        for i, (R, n) in enumerate(shapes):
+            key = (R, n, i % distinct)
+            if key not in self.made:
+                lay = synth.make_layer_device(R, n, 1000 + i, env.device)
+                self.made[key] = {k: lay[k] for k in ("W", "H", "scale", "mean")}
+            self.layers.append(self.made[key])
+        torch.cuda.synchronize()
+        self.t_setup = time.time() - t0
+        # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: one loop stream; the batched
+        # rounds run on the factor streams.  From 4 ranks up a rank factors one or two layers per step: TWO factor streams and
+        # the batched rounds on a loop stream of their own measured best -- one rank's step of the headline batch,
+        # tools/micro_rank_of_n.py with ROUNDS_ON_FS / NF / NL: N = 8: 4.3 ms against 4.7 with the rounds on the factor
+        # streams and 5.1 ... 5.4 with three factor streams; N = 4: 7.9 against 8.5 ... 9.8; N = 2 keeps three factor
+        # streams and rounds on them, 14.8 against 15.4)
+        few_factors = world >= 4
+        launch_bound = self.widest <= 1024 and world == 1
+        self.streams = streams or ((3, 3) if launch_bound else ((2, 1) if few_factors else (3, 1)))
+        self.backend = sdist.HipBackend(self.cb, "diag", 0.01, moves, with_error=True, overlap=self.streams)
+        if few_factors:
+            self.backend.rounds_on_factor_streams = False
+        self.in_flight = []  # per enqueued step: events at the tail of its streams
+
+    # -- the step
+    def strip_mean(self, lay):
         """a2, remove_input_bias (obq.py:14-25): part of cfg3's path, so inside the step."""
+        from sleekit_amd import _device as dev
+        from sleekit_amd import _lib
+
         n = lay["H"].shape[0]
         out = torch.empty_like(lay["H"])
         _lib.check(_lib.lib.slk_hessian_strip_mean(dev.ptr(lay["H"]), dev.ptr(lay["mean"]), n, dev.ptr(out), dev.stream_handle()))
         return dict(lay, H=out)
 
-    def step(stream_layers=None, be=None):
-        if args.graphs:
-            return step_graphs()
-        todo = layers if stream_layers is None else stream_layers
-        if strip:
-            todo = [strip_mean(lay) for lay in todo]
+    def step(self, stream_layers=None, be=None):
+        from sleekit_amd import dist as sdist
+
+        todo = self.layers if stream_layers is None else stream_layers
+        if self.strip:
+            todo = [self.strip_mean(lay) for lay in todo]
         # join=False: consecutive steps are independent batches, so the next step's factorisations start under
-        # this step's loops (the fence below waits for everything before the clock stops)
-        shards = sdist.quantize_stream(todo, be or backend, join=False)
+        # this step's loops (the fence waits for everything before the clock stops); the factorisation statuses of every
+        # layer are registered and checked after the timed region (raise_pending)
+        shards = sdist.quantize_stream(todo, be or self.backend, join=False)
         # flow control only: the host enqueues a step several times faster than the GPU runs it, and every step in
         # flight holds its own factors and outputs (2-3 GB); never more than four steps ahead
-        fstreams, _, lstreams = (be or backend).streams()
+        fstreams, _, lstreams = (be or self.backend).streams()
         if lstreams:
             evs = []
             for st in lstreams + fstreams:
                 e = torch.cuda.Event()
                 e.record(st)
                 evs.append(e)
-            in_flight.append(evs)
-            if len(in_flight) > 4:
-                for e in in_flight.pop(0):
+            self.in_flight.append(evs)
+            if len(self.in_flight) > 4:
+                for e in self.in_flight.pop(0):
                     e.synchronize()
         return shards
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(n_steps, n_warm, stream_layers=None):
+    def timed(self, n_steps, n_warm, stream_layers=None):
+        env = self.env
         for _ in range(n_warm):
-            step(stream_layers)
-        fence()
+            self.step(stream_layers)
+        env.fence()
         t0 = time.perf_counter()
         for _ in range(n_steps):
-            out = step(stream_layers)
-        fence()
+            out = self.step(stream_layers)
+        env.fence()
         el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=device)
+        if env.world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=env.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, out
 
-    elapsed, shards = timed(args.steps, args.warmup)
-    dev.raise_pending()
-    peak_hbm = torch.cuda.max_memory_reserved(device)  # after the timed region (at most five steps in flight)
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = weights_per_step / (elapsed / args.steps) / 1e6
+    # -- measurements
+    def layer_errors(self, shards):
+        """Layer error of EVERY layer of a step (mean over all rows; a scalar all-reduce per layer on N > 1 ranks)."""
+        from sleekit_amd import dist as sdist
 
-    # layer error of the last step (sanity: finite, GPTQ-sized) -- bookkeeping, not timed
-    err0 = float(sdist.layer_error(shards[0]["row_err"], shapes[0][0]).item())
+        vals = torch.stack([sdist.layer_error(sh["row_err"], self.shapes[i][0]) for i, sh in enumerate(shards)])
+        return [float(x) for x in vals.cpu().tolist()]
 
-    # ---- roofline of the dominant kernel: the SAME K steps once more (same streams, same overlap)
-    #      with a pair of HIP events around every launch, recorded on the launch's own stream
-    roofline, table = None, []
-    if not args.no_profile:
-        fence()
+    def profile(self, n_steps, full):
+        """The SAME steps once more (same streams, same overlap) with a pair of HIP events around every launch, recorded on
+        the launch's own stream; then (one rank) one single-stream step: every kernel alone on the chip."""
+        from sleekit_amd import _lib
+        from sleekit_amd import dist as sdist
+
+        env, args = self.env, self.env.args
+        env.fence()
         _lib.lib.slk_profile_reset()
         _lib.lib.slk_profile_enable(1)
+        if env.world > 1:
+            self.backend.exchange_log = []
         t0p = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
+        for _ in range(n_steps):
+            self.step()
+        env.fence()
         t_prof = time.perf_counter() - t0p
         _lib.lib.slk_profile_enable(0)
         table = _lib.profile_report()
         _lib.lib.slk_profile_reset()
+        exchange = None
+        if env.world > 1:
+            log, self.backend.exchange_log = self.backend.exchange_log, None
+            if log:
+                exchange = dict(ms_per_step=sum(a.elapsed_time(b) for a, b, _ in log) / n_steps, bytes_per_step=sum(x[2] for x in log) / n_steps,
+                                collectives_per_step=len(log) / n_steps)
         traffic_db, traffic_src = {}, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if full and os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic_db = tj.get("bytes_per_launch", {})
             traffic_src = f"profiles/pmc_traffic.json ({tj.get('made_by', 'tools/profile_round.sh')}, commit {tj.get('commit', 'unrecorded')}): " \
                           "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the headline batch, not measured in this run"
         seq = []
-        if world == 1 and table:
-            # the same kernels with the chip to themselves: one more pass on ONE stream (no kernel shares the CUs)
+        if env.world == 1 and table:
             _lib.lib.slk_profile_enable(1)
-            step(be=sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True, overlap=False))
+            self.step(be=sdist.HipBackend(self.cb, "diag", 0.01, self.moves, with_error=True, overlap=False))
             torch.cuda.synchronize()
             _lib.lib.slk_profile_enable(0)
             seq = _lib.profile_report()
             _lib.lib.slk_profile_reset()
+        if not table:
+            return None, exchange, seq
+        for k in table + seq:
+            k.setdefault("chip_ms", k["total_ms"])
 
         def describe(k, tab):
             secs = k["total_ms"] * 1e-3
@@ -318,74 +309,228 @@ def main():
                 "share_of_kernel_time": round(k["total_ms"] / sum(x["total_ms"] for x in tab), 3),
             }
 
-        if table:
-            # "dominant" = most CHIP time in the timed configuration: a launch's duration weighs by the share of the
-            # 256 CUs it can occupy (chip_ms, from the library: min(1, workgroups / 256) x duration), so that the
-            # one-workgroup latency chains of the factorisation, which run beside the wide kernels of other layers,
-            # do not pose as the bottleneck of the step.  (Overlapped durations include queueing for CUs: `alone` below
-            # is the kernel's own rate.)
-            for k in table + seq:
-                k.setdefault("chip_ms", k["total_ms"])
-            top = max(table, key=lambda k: k["chip_ms"])
-            roofline = describe(top, table)
-            roofline["steps_with_events_ms"] = round(1e3 * t_prof / args.steps, 3)
+        # "dominant" = most CHIP time in the timed configuration: a launch's duration weighs by the share of the
+        # 256 CUs it can occupy (chip_ms, from the library: min(1, workgroups / 256) x duration), so that the
+        # one-workgroup latency chains of the factorisation, which run beside the wide kernels of other layers,
+        # do not pose as the bottleneck of the step.  (Overlapped durations include queueing for CUs: `alone` below
+        # is the kernel's own rate.)
+        top = max(table, key=lambda k: k["chip_ms"])
+        roofline = describe(top, table)
+        if not full:
+            for key in ("traffic_source", "peak_kind", "share_of_kernel_time", "algorithmic_per_launch", "launches"):
+                roofline.pop(key, None)
+        roofline["steps_with_events_ms"] = round(1e3 * t_prof / n_steps, 3)
 
-            # the other kernels of the step, same measurement (share of summed kernel time, roofline fraction)
-            def frac_of(k):
-                kd = KERNEL_DTYPE.get(k["kernel"])
-                tf = k["flops"] / PEAK[kd][0] if kd else 0.0
-                return max(tf, k["bytes"] / PEAK["hbm"][0]) / max(k["total_ms"] * 1e-3, 1e-12)
+        def frac_of(k):
+            kd = KERNEL_DTYPE.get(k["kernel"])
+            tf = k["flops"] / PEAK[kd][0] if kd else 0.0
+            return max(tf, k["bytes"] / PEAK["hbm"][0]) / max(k["total_ms"] * 1e-3, 1e-12)
 
-            tot_ms = sum(k["total_ms"] for k in table)
-            tot_chip = sum(k["chip_ms"] for k in table)
-            roofline["top_kernels"] = [
-                {"kernel": k["kernel"], "chip_share": round(k["chip_ms"] / tot_chip, 3), "time_share": round(k["total_ms"] / tot_ms, 3),
-                 "frac": round(frac_of(k), 4), "avg_launch_us": round(1e3 * k["total_ms"] / k["launches"], 2)}
-                for k in sorted(table, key=lambda k: -k["chip_ms"])[:8]
-            ]
+        tot_ms = sum(k["total_ms"] for k in table)
+        tot_chip = sum(k["chip_ms"] for k in table)
+        roofline["top_kernels"] = [
+            {"kernel": k["kernel"], "chip_share": round(k["chip_ms"] / tot_chip, 3), "time_share": round(k["total_ms"] / tot_ms, 3),
+             "frac": round(frac_of(k), 4), "avg_launch_us": round(1e3 * k["total_ms"] / k["launches"], 2)}
+            for k in sorted(table, key=lambda k: -k["chip_ms"])[:8 if full else 5]
+        ]
         if seq:
-            # In the timed region kernels of several layers share the CUs, which stretches every launch; this is the
-            # kernel's own rate.
             alone = next((k for k in seq if k["kernel"] == roofline["kernel"]), None)
             if alone:
                 d = describe(alone, seq)
                 roofline["alone"] = {"avg_launch_us": d["avg_launch_us"], "achieved": d["achieved"], "frac": d["frac"],
-                                     "share_of_chip_time": d["share_of_chip_time"],
-                                     "note": "single-stream pass after the timed region: no other kernel shares the chip"}
+                                     "share_of_chip_time": d["share_of_chip_time"]}
+                if full:
+                    roofline["alone"]["note"] = "single-stream pass after the timed region: no other kernel shares the chip"
+
             # the whole error-update loop (SURVEY.md 8 a8 + a9: leaf chains and every blocked update = window + trailing
             # kernels; north_star prices the loop as one thing): its algorithmic float64 flops over the summed launch time
             def loop_rate(tab):
-                ks = [k for k in tab if k["kernel"] in ("gptq_window", "gptq_window_wide", "gptq_trailing")]
-                ms, fl = sum(k["total_ms"] for k in ks), sum(k["flops"] for k in ks)
-                return ms, fl
+                ks = [k for k in tab if k["kernel"] in LOOP_KERNELS]
+                return sum(k["total_ms"] for k in ks), sum(k["flops"] for k in ks)
+
             ms_a, fl_a = loop_rate(seq)
             ms_t, fl_t = loop_rate(table)
             if ms_a > 0 and ms_t > 0:
                 peak64 = PEAK["mfma_f64"][0]
                 roofline["loop"] = {
                     "kernels": "gptq_window + gptq_trailing", "bound": "mfma", "peak": peak64 / 1e12, "unit": "TFLOP/s",
-                    "algorithmic_flops_per_layer": fl_a / L,
-                    "alone": {"ms_per_layer": round(ms_a / L, 4), "achieved": round(fl_a / ms_a / 1e9, 3), "frac": round(fl_a / ms_a / 1e9 / (peak64 / 1e12), 4)},
-                    "timed": {"ms_per_layer": round(ms_t / args.steps / L, 4), "achieved": round(fl_t / ms_t / 1e9, 3),
-                              "frac": round(fl_t / ms_t / 1e9 / (peak64 / 1e12), 4),
-                              "note": "launch durations while other layers' kernels share the CUs"},
+                    "algorithmic_flops_per_layer": fl_a / self.L,
+                    "alone": {"ms_per_layer": round(ms_a / self.L, 4), "achieved": round(fl_a / ms_a / 1e9, 3), "frac": round(fl_a / ms_a / 1e9 / (peak64 / 1e12), 4)},
+                    "timed": {"ms_per_layer": round(ms_t / n_steps / self.L, 4), "achieved": round(fl_t / ms_t / 1e9, 3),
+                              "frac": round(fl_t / ms_t / 1e9 / (peak64 / 1e12), 4)},
                 }
+                if full:
+                    roofline["loop"]["timed"]["note"] = "launch durations while other layers' kernels share the CUs"
             lead = max(seq, key=lambda k: k["chip_ms"])
             if lead["kernel"] != roofline["kernel"]:
                 d = describe(lead, seq)
-                roofline["single_stream_leader"] = {k: d[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                                      "avg_launch_us", "algorithmic_per_launch", "share_of_chip_time")}
-        if args.stages and rank == 0 and world == 1 and table:
+                keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_per_launch", "share_of_chip_time")
+                roofline["single_stream_leader"] = {k: d[k] for k in (keys if full else ("kernel", "frac", "avg_launch_us", "share_of_chip_time"))}
+            if full:
+                tot_seq = sum(k["total_ms"] for k in seq)
+                roofline["single_stream_ms_per_layer"] = {k["kernel"]: round(k["total_ms"] / self.L, 4)
+                                                          for k in sorted(seq, key=lambda k: -k["total_ms"])[:10]}
+                roofline["single_stream_ms_per_layer"]["all kernels"] = round(tot_seq / self.L, 4)
+        if args.stages and env.rank == 0 and env.world == 1 and seq:
             tot = sum(k["total_ms"] for k in seq)
-            print(f"  single-stream pass: {tot:.3f} ms of kernels for {L} layers", file=sys.stderr)
+            print(f"  [{self.tag}] single-stream pass: {tot:.3f} ms of kernels for {self.L} layers", file=sys.stderr)
             for k in sorted(seq, key=lambda k: -k["total_ms"]):
                 print(
                     f"  {k['kernel']:<20s} {k['launches']:5d} launches {k['total_ms']:9.3f} ms {100 * k['total_ms'] / tot:5.1f}%"
                     f"  {k['flops'] / max(k['total_ms'], 1e-9) / 1e9:9.2f} TFLOP/s {k['bytes'] / max(k['total_ms'], 1e-9) / 1e6:9.1f} GB/s",
                     file=sys.stderr,
                 )
+        return roofline, exchange, seq
 
-    extras = rank == 0 and world == 1 and not args.no_extras and not args.graphs
+    def cpu_baseline(self, shards, sample_layers, best_of):
+        """The oracle on the host cores for `sample_layers` = [(layer index, count in the model)], each timed `best_of` times
+        after ONE warm-up of LAPACK / BLAS; rate = weights of the sample (x counts) / its time (x counts).  Where the oracle
+        ran a layer, its error is held against the GPU's for the same rows."""
+        from oracle import grid, obq_ref, scaling_ref
+        from sleekit_amd import synth
+
+        g = grid.UniformGrid(self.levels, -1, 1)
+        small = synth.make_layer(512, 512, 999)
+        scaling_ref.quantize_scaled(small["W"], small["scale"], g, small["H"])  # LAPACK/BLAS warm-up
+        tot_w = tot_t = 0.0
+        parts, checks = [], []
+        for idx, count in sample_layers:
+            R, n = self.shapes[idx]
+            rows = min(R, 512) if n > 8192 else R  # (the n^3 factorisation of an 11008-column layer alone is most of a minute)
+            lay = self.layers[idx]
+            host = {k: (lay[k][:rows] if k in ("W", "scale") else lay[k]).cpu().numpy() for k in ("W", "H", "scale", "mean")}
+            best, e_cpu = None, None
+            for _ in range(best_of):
+                t1 = time.perf_counter()
+                H0 = obq_ref.strip_input_mean(host["H"], host["mean"]) if self.strip else host["H"]
+                out = scaling_ref.quantize_scaled(host["W"], host["scale"], g, H0, "diag", 0.01, self.moves)
+                e_cpu = float(obq_ref.mean_error(host["W"], out, H0))
+                t = time.perf_counter() - t1
+                best = t if best is None else min(best, t)
+            tot_w += count * rows * n
+            tot_t += count * best
+            parts.append(f"{rows}x{n}" + (f" (first {rows} rows of {R})" if rows != R else "") + f" x{count}: {best:.2f} s")
+            e_gpu = float(shards[idx]["row_err"][:rows].double().mean().item())
+            checks.append({"layer": idx, "shape": [rows, n], "cpu": e_cpu, "gpu": e_gpu, "rel_diff": abs(e_gpu - e_cpu) / abs(e_cpu)})
+        cpu = {
+            "value": round(tot_w / tot_t / 1e6, 3), "unit": "Mweights/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"one layer per distinct shape, weighted by its count in the model: {'; '.join(parts)}; best of {best_of} after a 512x512 warm-up; "
+                      f"quantize_with_scaling + quantization_error, {self.levels} levels, moves={self.moves}{', H - m m^T' if self.strip else ''}, "
+                      f"NumPy {np.__version__} OpenBLAS threads=all",
+        }
+        return cpu, checks
+
+    def release(self):
+        from sleekit_amd import _device as dev
+
+        torch.cuda.synchronize()
+        self.layers, self.made, self.backend, self.in_flight = [], {}, None, []
+        dev.release_workspaces()
+        torch.cuda.empty_cache()
+
+
+def distinct_shape_sample(shapes):
+    """[(index of the first layer of each distinct shape, how many layers have it)] in order of appearance."""
+    first, count = {}, {}
+    for i, sh in enumerate(shapes):
+        first.setdefault(sh, i)
+        count[sh] = count.get(sh, 0) + 1
+    return [(first[sh], count[sh]) for sh in first]
+
+
+def config_leg(env, name):
+    """One BASELINE config as a short leg: value, roofline (compact), CPU baseline, layer-error check."""
+    from sleekit_amd import _device as dev
+
+    args = env.args
+    wl = WORKLOADS[name]
+    steps, warm, blocks = CONFIG_LEGS[name]
+    shapes = wl["block"] * (blocks or wl["blocks"])
+    leg = Leg(env, name, shapes, wl["levels"], wl["moves"], wl["strip"])
+    try:
+        elapsed, shards = leg.timed(steps, warm)
+        dev.raise_pending()
+        errs = leg.layer_errors(shards)
+        out = {
+            "workload": f"{wl['name']} in model order" + (f", first {len(shapes)} of {len(wl['block']) * wl['blocks']} layers" if blocks else "")
+                        + f", {wl['levels']} levels, moves={wl['moves']}{', H - m m^T' if wl['strip'] else ''}",
+            "value": round(leg.weights_per_step / (elapsed / steps) / 1e6, 2), "unit": "Mweights/s", "ms_per_step": round(1e3 * elapsed / steps, 3),
+            "steps": steps, "warmup": warm, "layers": len(shapes), "setup_seconds": round(leg.t_setup, 1),
+            "layer_errors": {"layers": len(errs), "all_finite": bool(np.all(np.isfinite(errs))), "min": min(errs), "max": max(errs)},
+        }
+        if not args.no_profile:
+            roofline, exchange, _ = leg.profile(min(steps, 2), full=False)
+            dev.raise_pending()
+            out["roofline"] = roofline
+            if exchange:
+                out["exchange"] = {k: round(v, 3) for k, v in exchange.items()}
+        if env.rank == 0 and env.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"], out["layer_errors"]["against_cpu"] = leg.cpu_baseline(shards, distinct_shape_sample(shapes), 1)
+        return out
+    finally:
+        leg.release()
+
+
+def main():
+    args = parse()
+    env = Env(args)
+    if args.config:
+        wl = dict(WORKLOADS[args.config])
+        if args.blocks:
+            wl["blocks"] = args.blocks
+        shapes = wl["block"] * wl["blocks"]
+        levels, moves, strip = wl["levels"], wl["moves"], wl["strip"]
+    else:
+        shapes = [(args.rows, args.cols)] * args.layers
+        levels, moves, strip = args.levels, args.moves, False
+    widest = max(n for _, n in shapes)
+    run_configs = not args.config and not args.no_configs
+    # small shapes alone (see the note on hardware queues at the top); with the config legs in the same process: 8 queues
+    env.start(launch_bound=widest <= 1024 and env.world == 1 and not run_configs)
+    rank, world, device = env.rank, env.world, env.device
+
+    from sleekit_amd import _device as dev
+    from sleekit_amd import _lib
+    from sleekit_amd import dist as sdist
+
+    dev.lazy_errors = True
+    streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else None
+    head = Leg(env, args.config or "headline", shapes, levels, moves, strip, streams=streams, distinct=args.distinct)
+    L = head.L
+
+    elapsed, shards = head.timed(args.steps, args.warmup)
+    dev.raise_pending()  # a Hessian that is not positive definite in any layer of any step: LinAlgError naming the layer
+    peak_hbm = torch.cuda.max_memory_reserved(device)  # after the timed region (at most five steps in flight)
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = head.weights_per_step / (elapsed / args.steps) / 1e6
+
+    # layer error of EVERY layer of the last step (sanity: finite, GPTQ-sized) -- bookkeeping, not timed
+    errs = head.layer_errors(shards)
+    assert all(np.isfinite(errs)), errs
+    layer_errors = {"layers": len(errs), "all_finite": True, "min": min(errs), "max": max(errs)}
+    if len(errs) <= 16:
+        layer_errors["values"] = errs
+
+    roofline, exchange = None, None
+    if not args.no_profile:
+        roofline, exchange, _ = head.profile(args.steps, full=True)
+        dev.raise_pending()
+
+    # ---- N > 1: what the collective did, and that every rank received its roots' bytes
+    rccl = None
+    if world > 1:
+        check = sdist.verify_exchange(head.layers if not strip else [head.strip_mean(lay) for lay in head.layers], head.backend)
+        env.fence()
+        rccl = {"world_size": check["world_size"], "backend": check["backend"], "payload_bytes": check["payload_bytes"],
+                "payload_checksums_agree": check["agree"], "rounds_checked": check["rounds_checked"]}
+        if exchange:
+            rccl.update(all_gather_bytes_per_step=int(exchange["bytes_per_step"]), exchange_ms=round(exchange["ms_per_step"], 3),
+                        collectives_per_step=exchange["collectives_per_step"],
+                        note="bytes a rank RECEIVES per step; exchange_ms = summed duration of the step's all-gathers, events on the comm "
+                             "stream, in the pass repeated with events (it overlaps the loops of the round before)")
+        assert check["agree"], "a rank's copy of a packed factor differs from its root's"
+
+    extras = rank == 0 and world == 1 and not args.no_extras
     # ---- one isolated layer, start to finish (SURVEY.md 8e: "report the single-layer number separately")
     latency = None
     if extras:
@@ -395,10 +540,10 @@ def main():
 
         lat = []
         for i in range(6):
-            lay = strip_mean(layers[i % L]) if strip else layers[i % L]
+            lay = head.strip_mean(head.layers[i % L]) if strip else head.layers[i % L]
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            res = engine.quantize_layer(lay["W"], lay["H"], cb, lay["scale"], "diag", 0.01, moves)
+            res = engine.quantize_layer(lay["W"], lay["H"], head.cb, lay["scale"], "diag", 0.01, moves)
             engine.row_errors(lay["W"], res.Q, lay["H"])
             torch.cuda.synchronize()
             lat.append(1e3 * (time.perf_counter() - t1))
@@ -413,7 +558,7 @@ def main():
         n = args.cols
         alt = {}
         gemm_symmetric = True
-        for i, lay in enumerate(layers):
+        for i, lay in enumerate(head.layers):
             if id(lay) not in alt:
                 X = torch.randn(2 * n, n, device=device) * (0.5 + 2.0 * torch.rand(n, device=device))
                 X[:, :8] *= 8.0
@@ -424,11 +569,11 @@ def main():
                 gemm_symmetric = gemm_symmetric and bool(torch.equal(Ha, Ha.T))
                 Ha = Ha + torch.triu(torch.randn_like(Ha), 1) * (1e-6 * float(Ha.abs().mean()))
                 alt[id(lay)] = dict(lay, H=Ha)
-        alt_layers = [alt[id(lay)] for lay in layers]
+        alt_layers = [alt[id(lay)] for lay in head.layers]
         symmetric = all(bool(torch.equal(a["H"], a["H"].T)) for a in alt.values())
-        el, _ = timed(args.steps, 1, alt_layers)
+        el, _ = head.timed(args.steps, 1, alt_layers)
         dev.raise_pending()
-        asym = {"value": round(weights_per_step / (el / args.steps) / 1e6, 2), "unit": "Mweights/s", "ms_per_layer": round(1e3 * el / args.steps / L, 3),
+        asym = {"value": round(head.weights_per_step / (el / args.steps) / 1e6, 2), "unit": "Mweights/s", "ms_per_layer": round(1e3 * el / args.steps / L, 3),
                 "H": "torch X.T @ X / T in float32 + 1e-6 relative noise above the diagonal", "bitwise_symmetric": symmetric,
                 "library_gemm_result_was_symmetric": gemm_symmetric}
         del alt, alt_layers
@@ -456,55 +601,80 @@ def main():
         hess = {"features": n, "tokens_per_batch": 2048, "ms_per_batch": round(ms, 3), "achieved_tflops": round(flops / ms / 1e9, 2),
                 "peak_tflops": PEAK["mfma_f32"][0] / 1e12, "frac": round(flops / ms / 1e9 / (PEAK["mfma_f32"][0] / 1e12), 4),
                 "algorithmic_flops": "T n (n + 1): one triangle, float32 by definition; executed as six bfloat16 products each when n % 128 == 0"}
+        del Hacc, macc, X
 
-    # ---- CPU baseline: the oracle on the host cores, one layer of the same workload
+    # ---- CPU baseline: the oracle on the host cores, one layer of the same workload (best of 3), or one per shape
     cpu = None
-    if host_layer0 is not None:
-        from oracle import grid, obq_ref, scaling_ref
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample = distinct_shape_sample(shapes) if args.config else [(0, 1)]
+        cpu, checks = head.cpu_baseline(shards, sample, 1 if args.config else 3)
+        layer_errors["against_cpu"] = checks
+        cpu["layer_error"], cpu["gpu_layer_error"] = checks[0]["cpu"], checks[0]["gpu"]
 
-        g = grid.UniformGrid(levels, -1, 1)
-        small = synth.make_layer(512, 512, 999)
-        scaling_ref.quantize_scaled(small["W"], small["scale"], g, small["H"])  # LAPACK/BLAS warm-up
-        t1 = time.perf_counter()
-        H0 = obq_ref.strip_input_mean(host_layer0["H"], host_layer0["mean"]) if strip else host_layer0["H"]
-        out = scaling_ref.quantize_scaled(host_layer0["W"], host_layer0["scale"], g, H0, "diag", 0.01, moves)
-        e_cpu = float(obq_ref.mean_error(host_layer0["W"], out, H0))
-        t_cpu = time.perf_counter() - t1
-        R0, n0 = host_layer0["W"].shape
-        cpu = {
-            "value": round(R0 * n0 / t_cpu / 1e6, 3), "unit": "Mweights/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"1 layer {R0}x{n0} (inputs of GPU layer 0{'' if R0 == shapes[0][0] else ', first ' + str(R0) + ' rows'}), quantize_with_scaling + "
-                      f"quantization_error, {levels} levels, moves={moves}, NumPy {np.__version__} OpenBLAS threads=all, after a 512x512 warm-up; {t_cpu:.2f} s",
-            "layer_error": e_cpu, "gpu_layer_error": err0 if R0 == shapes[0][0] else None,
-        }
+    if args.config:
+        wl = WORKLOADS[args.config]
+        metric = f"Mweights/sec quantized ({wl['name']}, {np.log2(levels):.3g}-bit)"
+        workload = (f"{args.config}: {wl['name']} in model order, {L} layers, {levels}-level uniform codebook, act_order=diag, damp=0.01, "
+                    f"local-search moves={moves}, {'H - m m^T, ' if strip else ''}layer error included")
+    else:
+        metric = "Mweights/sec quantized (GPTQ 3-bit, 4096x4096 layer)"
+        workload = (f"{L} layers {args.rows}x{args.cols}, {levels}-level uniform codebook (GPTQ {np.log2(levels):g}-bit), "
+                    f"act_order=diag, damp=0.01, local-search moves={moves}, layer error included")
+    line = {
+        "metric": metric, "value": round(value, 2), "unit": "Mweights/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": workload, "layers_per_step": L, "distinct_inputs": len(head.made),
+            "shapes": sorted({f"{R}x{n}" for R, n in shapes}), "row_sharding": f"{world} ranks",
+            "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(head.t_setup, 1),
+            "peak_hbm_gb": round(peak_hbm / 2**30, 2),
+            "streams": {"factor": head.streams[0], "loop": head.streams[1]},
+            "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+        },
+        "roofline": roofline, "cpu_baseline": cpu, "layer_error": errs[0], "layer_errors": layer_errors, "latency_ms_single_layer": latency,
+        "asymmetric_H": asym, "hessian_accumulate": hess,
+    }
+    if rccl:
+        line["rccl"] = rccl
 
-    if rank == 0:
-        if args.config:
-            wl = WORKLOADS[args.config]
-            metric = f"Mweights/sec quantized ({wl['name']}, {np.log2(levels):.3g}-bit)"
-            workload = (f"{args.config}: {wl['name']} in model order, {L} layers, {levels}-level uniform codebook, act_order=diag, damp=0.01, "
-                        f"local-search moves={moves}, {'H - m m^T, ' if strip else ''}layer error included")
-        else:
-            metric = "Mweights/sec quantized (GPTQ 3-bit, 4096x4096 layer)"
-            workload = (f"{L} layers {args.rows}x{args.cols}, {levels}-level uniform codebook (GPTQ {np.log2(levels):g}-bit), "
-                        f"act_order=diag, damp=0.01, local-search moves={moves}, layer error included")
-        line = {
-            "metric": metric, "value": round(value, 2), "unit": "Mweights/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": workload, "layers_per_step": L, "distinct_inputs": len(made),
-                "shapes": sorted({f"{R}x{n}" for R, n in shapes}), "row_sharding": f"{world} ranks",
-                "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(t_setup, 1),
-                "peak_hbm_gb": round(peak_hbm / 2**30, 2),
-                "streams": {"factor": streams[0], "loop": streams[1]}, "hip_graphs": bool(args.graphs),
-                "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-            },
-            "roofline": roofline, "cpu_baseline": cpu, "layer_error": err0, "latency_ms_single_layer": latency,
-            "asymmetric_H": asym, "hessian_accumulate": hess,
-        }
-        print(json.dumps(line))
+    # ---- the other BASELINE configs, a short leg each.  The headline above is complete: whatever happens in a leg (an
+    #      exception, or on N > 1 ranks a collective that never returns) the line is printed -- a watchdog prints it and
+    #      ends the process if the legs take longer than their allowance.
+    printed = threading.Event()
+
+    def emit():
+        if not printed.is_set():
+            printed.set()
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+
+    if run_configs:
+        head.release()
+        names = [c for c in (args.configs.split(",") if args.configs else sorted(CONFIG_LEGS)) if c in CONFIG_LEGS]
+        line["configs"] = {}
+        allowance = float(os.environ.get("SLK_BENCH_CONFIGS_SECONDS", "420"))
+
+        def bail():
+            line["configs"]["error"] = f"config legs exceeded {allowance:.0f} s; stopped"
+            emit()
+            os._exit(0)
+
+        dog = threading.Timer(allowance, bail)
+        dog.daemon = True
+        dog.start()
+        t_legs = time.time()
+        for name in names:
+            try:
+                line["configs"][name] = config_leg(env, name)
+            except Exception as exc:  # the headline stands; the leg says what went wrong
+                line["configs"][name] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+                if world > 1:
+                    break  # the ranks are out of step: no further collectives
+        line["configs"]["seconds"] = round(time.time() - t_legs, 1)
+        dog.cancel()
+    emit()
     if world > 1:
         dist.destroy_process_group()
 

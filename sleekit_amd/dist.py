@@ -554,7 +554,18 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
                 else:  # no layer of this round is this rank's: contribute a blank
                     dev_ = comm_device if comm_device is not None else layers[0]["H"].device
                     payload = backend.alloc_payload(words, dev_).zero_()
-                gathered[g] = _all_gather_words(payload, size)
+                log = getattr(backend, "exchange_log", None)
+                if log is not None and payload.is_cuda:
+                    # measurement (bench.py's pass with events): the comm stream brackets the collective with two events
+                    # and waits for it, so that their distance is the exchange itself
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(torch.cuda.current_stream())
+                    gathered[g] = _all_gather_words(payload, size)
+                    gathered[g][1].wait()
+                    e1.record(torch.cuda.current_stream())
+                    log.append((e0, e1, payload.numel() * payload.element_size() * (size - 1)))
+                else:
+                    gathered[g] = _all_gather_words(payload, size)
                 keep.append(payload)
     # 3. every rank runs its rows of every layer as the factors land, round by round.  A round goes through the
     #    kernels as ONE batch when the backend can do that (run_round): the shards are R / G rows each, too few to
@@ -626,6 +637,42 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
             for t in shard.values():
                 if isinstance(t, torch.Tensor):
                     t.record_stream(here)
+    return out
+
+
+def verify_exchange(layers, backend, max_rounds=2):
+    """Self-check of the collective: for the first rounds of the stream, every rank packs the factor of its own layer,
+    the payloads are all-gathered exactly as quantize_stream does, and every rank's copy of every payload is held to its
+    ROOT's own buffer by two wrapping int64 checksums (plain and position-weighted), compared across ranks through a
+    second, tiny all-gather.  Returns dict(world_size, backend, rounds_checked, payload_bytes, agree)."""
+    rank, size = world()
+    out = dict(world_size=size, backend=dist.get_backend() if size > 1 and rehearse is None else "none", rounds_checked=0,
+               payload_bytes=0, agree=True)
+    if size <= 1 or rehearse is not None:
+        return out
+    rounds, root = plan_rounds(layers, size)
+    for members in rounds[:max_rounds]:
+        words = max(backend.payload_words(layers[j]["H"].shape[0]) for j in members)
+        own = [l for l in members if root[l] == rank]
+        payload = backend.pack(backend.factorize(layers[own[0]]), words) if own else backend.alloc_payload(words, layers[0]["H"].device).zero_()
+        parts, work = _all_gather_words(payload, size)
+        work.wait()
+        weight = torch.arange(1, words + 1, dtype=torch.int64, device=payload.device)
+
+        def sums(t):
+            return torch.stack([t.sum(), (t * weight).sum()])
+
+        seen = torch.stack([sums(p) for p in parts])  # (size, 2): this rank's view of every rank's payload
+        views = [torch.empty_like(seen) for _ in range(size)]
+        dist.all_gather(views, seen)
+        views = torch.stack(views).cpu()  # [viewer][source][2]
+        mine = sums(payload).cpu()
+        ok = bool(torch.equal(views[rank][rank], mine))
+        for src in range(size):
+            ok = ok and all(bool(torch.equal(views[viewer][src], views[src][src])) for viewer in range(size))
+        out["agree"] = out["agree"] and ok
+        out["rounds_checked"] += 1
+        out["payload_bytes"] = int(words * 8)
     return out
 
 

@@ -1065,31 +1065,6 @@ def test_symmetry_verdict_at_the_edges(amd, n):
         np.testing.assert_allclose(amd.obq.channelwise_error(W, Q, Ha), want, rtol=1e-5, atol=1e-5 * np.abs(want).max(), err_msg=str((i, j)))
 
 
-def test_graph_replay_of_a_layer(amd):
-    """sleekit_amd.graphs.GraphedLayer: the whole per-layer pipeline captured in a hipGraph, replayed with new
-    inputs -- same bits as the eager calls, for two different layers through the same graph."""
-    from sleekit_amd import graphs
-
-    cb = amd.codebook.UniformCodebook(8, -1, 1)
-    R, n = 96, 172
-    g = graphs.GraphedLayer(R, n, cb)
-    for seed in (2003, 2004, 2003):
-        L = layer(R, n, seed)
-        W, H, sc = (torch.from_numpy(L[k]).cuda() for k in ("W", "H", "scale"))
-        g(W, H, sc)
-        torch.cuda.synchronize()
-        g.check()
-        res = amd.engine.quantize_layer(W, H, cb, sc)
-        err = amd.engine.row_errors(W, res.Q, H)
-        assert torch.equal(g.Q, res.Q) and torch.equal(g.idx, res.idx) and torch.equal(g.row_err, err), seed
-    Hbad = torch.from_numpy(layer(R, n, 2003)["H"]).cuda().clone()
-    Hbad[5, 5] = -1.0e6
-    g(H=Hbad)
-    torch.cuda.synchronize()
-    with pytest.raises(np.linalg.LinAlgError):
-        g.check()
-
-
 @pytest.mark.parametrize("n", [768, 1024, 1536, 2048, 3072, 4096])
 def test_scale_search_regular_tree(amd, slkopt, n):
     """Row lengths whose NumPy summation tree is regular (2^k leaves of <= 128 elements) take the chain-per-thread

@@ -9,13 +9,24 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$TAG
 rm -rf $OUT
 mkdir -p $OUT
-# 1. per-kernel time of the command the driver runs
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_under_rocprof.log 2>&1
+# 1. per-kernel time of the command the driver runs: its headline leg (--no-configs: the config legs get a CSV each below,
+#    so that a kernel's average is over launches of ONE workload)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-configs > $OUT/bench_under_rocprof.log 2>&1
 cp $OUT/stats/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats_default_bench.csv
 grep '"metric"' $OUT/bench_under_rocprof.log > $OUT/${TAG}_bench_line_under_rocprof.json
 echo "stats pass done"
+# 1b. one kernel-stats CSV per BASELINE config (the legs of the default run, as their own commands)
+for CFG in cfg2 cfg3 cfg4 cfg5; do
+  BLK=""; STEPS=3
+  if [ $CFG = cfg5 ]; then BLK="--blocks 16"; STEPS=2; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$CFG -- python3 bench.py --gpus 1 --config $CFG $BLK --steps $STEPS --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_${CFG}_under_rocprof.log 2>&1
+  cp $OUT/stats_$CFG/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats_${CFG}.csv
+  grep '"metric"' $OUT/bench_${CFG}_under_rocprof.log > $OUT/${TAG}_bench_line_${CFG}_under_rocprof.json
+  rm -rf $OUT/stats_$CFG
+  echo "stats pass $CFG done"
+done
 # 2. counters: one pass each, single-stream run of one step (every kernel alone on the chip)
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-extras --streams 1,1"
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-extras --no-configs --streams 1,1"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/fetch.log 2>&1
 echo "fetch pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/write.log 2>&1

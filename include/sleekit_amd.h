@@ -266,8 +266,9 @@ int slk_symmetry_flag(const float *H, int n, int *flag, slk_stream_t stream);
  *     the first move on at which the row had nothing left to gain (parity tests compare it with the
  *     reference's sequence of moves to find where, if anywhere, a near-tie fell the other way).  A "move" onto the
  *     value a weight already holds changes nothing and the reference repeats it until its moves run out: the search
- *     of that row ends there and the trace carries the repeats, as the reference's own record does.  (The carried
- *     gains of gains_mode 1 / 2 then lack the reference's additions of +0.0: at most the sign of a zero differs.)
+ *     of that row ends there and the trace says -1 ("stay") from that move on, where a record of the reference's own
+ *     do_move() calls would show the repeated non-move.  (The carried gains of gains_mode 1 / 2 then lack the reference's
+ *     additions of +0.0: at most the sign of a zero differs.)
  *     gains / gains_mode: the state of the reference's stateful LocalSearchQuantizer (obq.py:234-346) between calls --
  *     R x 2 x n float32, per row the n up-gains then the n down-gains.  gains_mode 0: none (gains may be NULL);
  *     1: the initial gains are built from (W - Q) H as usual, and the gains after the moves are stored (moves == 0

@@ -125,14 +125,10 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         // A "move" onto the value the weight already has (the up-candidate of the top level is the top level; a
         // rounding residue can leave such a candidate a positive gain): the reference carries it out, and every
         // term of its gain update (obq.py:322-334) is then a product with a zero difference -- Q and the gains stay as
-        // they are, so it repeats the same non-move until the moves run out.  Same final state: stop here, with the
-        // repeats written into the record of moves so that the trace is the reference's own.
-        if (q_new == q_old) {
-            if (trace && t == 0)
-                for (int m2 = mv; m2 < moves; ++m2) trace[(size_t)row * moves + m2] = 2 * c + (go_up ? 1 : 0);
-            mv = moves;  // (nothing left for the -1 fill below)
-            break;
-        }
+        // they are, so it repeats the same non-move until the moves run out.  Same final state: stop here.  The trace
+        // says -1 ("stay") from here on, the convention of the move records the parity tests hold it to
+        // (oracle/obq_ref.py: move_record counts the reference's non-moves as "stay").
+        if (q_new == q_old) break;
         if (trace && t == 0) trace[(size_t)row * moves + mv] = 2 * c + (go_up ? 1 : 0);
 
         // ---- stream row c of H: the products of the interaction sum with the OLD Q (obq.py:328), and part 2
@@ -281,12 +277,7 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
         const int c = go_up ? bu.j : bd.j;
         const float q_old = go_up ? bu.q : bd.q;
         const float q_new = go_up ? cand_up(q_old, g) : cand_down(q_old, g);
-        if (q_new == q_old) {  // a "move" onto the same value: see k_local_search
-            if (trace && tr == 0)
-                for (int m2 = mv; m2 < moves; ++m2) trace[(size_t)row * moves + m2] = 2 * c + (go_up ? 1 : 0);
-            mv = moves;  // (nothing left for the -1 fill below)
-            break;
-        }
+        if (q_new == q_old) break;  // a "move" onto the same value: see k_local_search
         if (trace && tr == 0) trace[(size_t)row * moves + mv] = 2 * c + (go_up ? 1 : 0);
 
         const float *hrow = H + (size_t)c * n;

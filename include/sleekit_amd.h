@@ -66,7 +66,8 @@ typedef void *slk_stream_t;
  * `trace` and `gains` arguments of slk_local_search, slk_set_option / slk_get_option and the batched factorisation
  * (slk_hessian_prepare_batch, slk_chol_inverse_upper_batch, slk_factor_workspace_bytes_batch); 5 adds codebook training
  * (slk_codebook_stats, slk_sort_f32, slk_unique_f32), slk_local_search_batch and slk_factor_unpack_upper_batch; 6 adds
- * slk_chol_inverse_upper_lookahead and slk_release_helpers (the look-ahead is an argument of the call, not a process-wide switch).                                                          */
+ * slk_chol_inverse_upper_lookahead and slk_release_helpers (the look-ahead is an argument of the call, not a process-wide switch)
+ * and turns the loop's `unscale` argument into `flags` (SLK_LOOP_UNSCALE = 1 as before, SLK_LOOP_LATENCY = 2).                                                          */
 int slk_abi_version(void);
 const char *slk_last_error(void);
 /* Run-time switches between code paths that give the same results (the tests hold them to that) or that shape a
@@ -74,7 +75,7 @@ const char *slk_last_error(void);
  * "no_error_splitk", "error_cb", "no_sym_error", "no_bf16_error", "no_bf16_dma", "no_bf16_hessian", "no_bf16_asym", "no_sym_average",
  * "error_f32_below", "no_wave_search", "lookahead" (EVERY factorisation forks the bulk of its outer updates onto a helper stream: a measurement
  * switch; one call at a time asks for it through slk_chol_inverse_upper_lookahead instead), "window_rows" (16 or 32 rows per
- * window workgroup; 0 = 16) (case-insensitive,
+ * window workgroup, forced; 0 = 32, or 16 under SLK_LOOP_LATENCY) (case-insensitive,
  * an "SLK_" prefix is accepted).  Initial values are read ONCE from the environment (SLK_NO_WINDOW2=1 ...);
  * afterwards only these calls change them.  Process-wide, thread-safe; no reference counterpart.              */
 int slk_set_option(const char *name, int value);
@@ -220,13 +221,18 @@ int slk_factor_unpack_upper_batch(const void *const *payloads, int batch, int n,
  *     the reference's recursion (min_block, num_blocks), float64 updates rounded to
  *     float32 at the reference's rounding points.
  *     order (may be NULL): identity, i.e. _quantize_opt_block on Q as given (obq.py:121-137).
- *     Q (R x n float32, original column order): codebook VALUES in the scaled domain, or -- unscale != 0,
+ *     Q (R x n float32, original column order): codebook VALUES in the scaled domain, or -- flags & SLK_LOOP_UNSCALE,
  *       scale given -- de-scaled like quantize_with_scaling's result (scaling.py:80: q / (1 / scale[r])).
+ *     flags: SLK_LOOP_UNSCALE | SLK_LOOP_LATENCY.  SLK_LOOP_LATENCY: this layer is alone on the GPU -- the window kernel
+ *       takes 16 rows per workgroup (shortest launch) instead of 32 (least chip time, for streams of layers whose kernels
+ *       overlap); the results are the same bit for bit.
  *     idx (may be NULL): codebook indices, uint8, original column order.
  *     E_out (may be NULL): the scaled errors E of obq.py:115, R x n, in PROCESSING order. */
+#define SLK_LOOP_UNSCALE 1
+#define SLK_LOOP_LATENCY 2
 int slk_gptq_quantize(const float *W, const float *scale, const long long *order, const double *U,
                       int R, int n, int levels, double lo, double hi, const float *table, int min_block,
-                      int num_blocks, int unscale, float *Q, uint8_t *idx, float *E_out, void *workspace,
+                      int num_blocks, int flags, float *Q, uint8_t *idx, float *E_out, void *workspace,
                       size_t ws_bytes, slk_stream_t stream);
 
 /* (e) The same loop over `batch` layers of one shape at once, stacked by rows: W, Q, idx, E_out are
@@ -238,7 +244,7 @@ int slk_gptq_quantize(const float *W, const float *scale, const long long *order
  *     Workspace: slk_workspace_bytes_batch(batch, rows_per_layer, n).                                       */
 int slk_gptq_quantize_batch(const float *W, const float *scale, const long long *order, const double *U,
                             int batch, int rows_per_layer, int n, int levels, double lo, double hi,
-                            const float *table, int min_block, int num_blocks, int unscale, float *Q,
+                            const float *table, int min_block, int num_blocks, int flags, float *Q,
                             uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes, slk_stream_t stream);
 size_t slk_workspace_bytes_batch(int batch, int rows_per_layer, int n);
 

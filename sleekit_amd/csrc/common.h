@@ -83,7 +83,7 @@ enum Opt {
     OPT_NO_SYM_AVERAGE,        // layer error: an H that is not symmetric is NOT averaged with its transpose (planes of H^T, every k, instead)
     OPT_NO_WAVE_SEARCH,        // local search: the workgroup-per-row kernel for every row length
     OPT_LOOKAHEAD,             // factorisation: the bulk of an outer syrk on a helper stream, beside the next block's panels
-    OPT_WINDOW_ROWS,           // window kernel: rows per workgroup, 16 (default) or 32 (half the CUs per launch, 1.55 times the duration)
+    OPT_WINDOW_ROWS,           // window kernel: rows per workgroup forced to 16 or 32 (0: 32, or 16 where the caller asks for latency)
     OPT_COUNT
 };
 int opt(Opt o);

@@ -857,9 +857,9 @@ extern "C" int slk_probe_window_cycles(long long *host_out, int reset) {
 
 extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long long *order, const double *U,
                                  int R, int n, int levels, double lo, double hi, const float *table, int min_block, int num_blocks,
-                                 int unscale, float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
+                                 int flags, float *Q, uint8_t *idx, float *E_out, void *workspace, size_t ws_bytes,
                                  slk_stream_t stream) {
-    return slk_gptq_quantize_batch(W, scale, order, U, 1, R, n, levels, lo, hi, table, min_block, num_blocks, unscale, Q, idx,
+    return slk_gptq_quantize_batch(W, scale, order, U, 1, R, n, levels, lo, hi, table, min_block, num_blocks, flags, Q, idx,
                                    E_out, workspace, ws_bytes, stream);
 }
 
@@ -868,9 +868,11 @@ extern "C" int slk_gptq_quantize(const float *W, const float *scale, const long 
 // the chip idle (the window kernel runs one workgroup per 16 rows), G layers' shards together fill it.
 extern "C" int slk_gptq_quantize_batch(const float *W, const float *scale, const long long *order, const double *U,
                                        int batch, int rows_per_layer, int n, int levels, double lo, double hi,
-                                       const float *table, int min_block, int num_blocks, int unscale, float *Q, uint8_t *idx,
+                                       const float *table, int min_block, int num_blocks, int flags, float *Q, uint8_t *idx,
                                        float *E_out, void *workspace, size_t ws_bytes, slk_stream_t stream) {
     SLK_REQUIRE(W && U && Q, "null pointer");
+    SLK_REQUIRE((flags & ~(SLK_LOOP_UNSCALE | SLK_LOOP_LATENCY)) == 0, "unknown flags");
+    const int unscale = flags & SLK_LOOP_UNSCALE;
     SLK_REQUIRE(!unscale || scale, "unscale needs the row scales");
     SLK_REQUIRE(rows_per_layer > 0 && n > 0, "empty layer");
     SLK_REQUIRE(batch >= 1 && batch <= 64, "batch must be 1..64");
@@ -901,18 +903,20 @@ extern "C" int slk_gptq_quantize_batch(const float *W, const float *scale, const
 #ifdef SLK_WINDOW_EXPERIMENTS
     const int dbg = opt(OPT_WIN_DBG);
 #else
-    const int dbg = opt(OPT_WIN_DBG) & (8 | 16 | 32);  // cycle counters, no L2 warm-up, whole tile loaded up front: same results
+    const int dbg = opt(OPT_WIN_DBG) & (8 | 16 | 32 | 64 | 128);  // cycle counters, no L2 warm-up, whole tile loaded up front: same results
 #endif
     const bool no_defer = opt(OPT_NO_DEFER) != 0;
     SLK_LDS_OPT_IN(k_gptq_window<true>, sizeof(WindowSmem));
     SLK_LDS_OPT_IN(k_gptq_window2<1>, sizeof(Window2SmemT<1>));
     SLK_LDS_OPT_IN(k_gptq_window2<2>, sizeof(Window2SmemT<2>));
-    // 32 rows per workgroup halve the CUs a window launch occupies but it lasts 1.55 times as long (114 against 73 us:
-    // two interleaved chains per wave issue twice the instructions, and a chain is issue-bound); in the pipelined bench
-    // the CUs it frees for the other streams and the longer loop chain cancel (4990 against 4980 Mweights/s), so 16 rows
-    // stay the default and 32 a switch (slk_set_option "window_rows")
-    const int window_rows = opt(OPT_WINDOW_ROWS) == 16 || opt(OPT_WINDOW_ROWS) == 32 ? opt(OPT_WINDOW_ROWS) : 16;
-    const bool periods_ok = n % 2 == 0 && n <= 16384 && (uintptr_t)U % 16 == 0 && !opt(OPT_NO_WINDOW2) && (dbg & ~24) == 0;
+    // 32 rows per workgroup (eight rows per chain wave, ONE quantizer instruction stream for them: leaf_chain8) halve the CUs
+    // a window launch occupies for 1.45 times the duration (96 against 66 us at 4096 rows): less chip time per row, which is
+    // what counts when other streams' kernels fill the CUs it leaves (round 3, every BASELINE stream on one MI355X: headline
+    // 5040 -> 5180 Mweights/s, OPT-125M 5350 -> 5700, OPT-350M 4430 -> 4650, BLOOM-560M 3620 -> 3860) -- the default.  16
+    // rows (four per chain wave) are faster for ONE layer alone: callers ask with SLK_LOOP_LATENCY (the single-layer API
+    // does).  slk_set_option("window_rows", 16 | 32) forces either.
+    const int window_rows = opt(OPT_WINDOW_ROWS) == 16 || opt(OPT_WINDOW_ROWS) == 32 ? opt(OPT_WINDOW_ROWS) : ((flags & SLK_LOOP_LATENCY) ? 16 : 32);
+    const bool periods_ok = n % 2 == 0 && n <= 16384 && (uintptr_t)U % 16 == 0 && !opt(OPT_NO_WINDOW2) && (dbg & ~(24 | 64 | 128)) == 0;
 
     // rows staged through LDS when they fit and 16-byte accesses line up
     const bool perm_lds = order && n % 4 == 0 && n <= PERM_MAX && ((uintptr_t)W | (uintptr_t)Q | (uintptr_t)workspace) % 16 == 0 &&
@@ -973,7 +977,7 @@ extern "C" int slk_gptq_quantize_batch(const float *W, const float *scale, const
                     if (window_rows == 32)
                         SLK_RUN_W("gptq_window", fl * R, wbytes, (R + 2 * RB - 1) / (2 * RB), s,
                                   k_gptq_window2<2><<<(R + 2 * RB - 1) / (2 * RB), 512, sizeof(Window2SmemT<2>), s>>>(
-                                      Qp, Eg, U, R, n, st.a, st.b, g, inv_step, fast_ok, dbg & 24, pt, rpl));
+                                      Qp, Eg, U, R, n, st.a, st.b, g, inv_step, fast_ok, dbg & (24 | 64 | 128), pt, rpl));
                     else
                         SLK_RUN_W("gptq_window", fl * R, wbytes, row_tiles, s,
                                   k_gptq_window2<1><<<row_tiles, 512, sizeof(Window2SmemT<1>), s>>>(Qp, Eg, U, R, n, st.a, st.b, g, inv_step,

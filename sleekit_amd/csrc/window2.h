@@ -36,9 +36,15 @@ struct PeriodTable {
 // of U -- so that a launch of R rows occupies R / 32 CUs for about the same time instead of R / 16: the chip time of
 // the window kernel per row drops by a third and the CUs it leaves go to the other streams' kernels.  The two U
 // blocks are single buffers then (158 KB again), guarded by two LDS counters instead of the buffer parity.
+struct LeafTables8 {
+    double u[ULEAF][ULEAF];  // leaf block of U, strictly upper part, columns permuted: [i][(j & 7) * 4 + (j >> 3)]
+    double udr[ULEAF][2];    // its diagonal (1 beyond the width) and 1 / diagonal by true division
+};
+
 template <int SETS>
 struct Window2SmemT {
-    LeafTables lt[2][2];                       // [period parity][leaf]
+    // [period parity][leaf]; SETS == 2: eight rows per chain wave (leaf_chain8), a lane's four columns side by side
+    typename std::conditional<SETS == 1, LeafTables, LeafTables8>::type lt[2][2];
     double sblk[SETS == 1 ? 2 : 1][16 * 64];   // U block of the update between the two leaves, in chunks of 4 k x 16 columns
     double nblk[SETS == 1 ? 2 : 1][64 * 64];   // U block of the update into the next period, same chunking
     float q[RB * SETS][WPITCH];
@@ -128,6 +134,83 @@ __device__ __forceinline__ void leaf_chain(const LeafTables &lt, int c16, float 
     }
 }
 
+// lane S of every 8-lane group, to all lanes of that group: row_newbcast of lane S over the 16-lane DPP row, then lanes
+// 8-15 of the row (bank mask 0xC) take lane 8 + S instead
+template <int S>
+__device__ __forceinline__ float bcast8(float x) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + S, 0xf, 0xf, true);
+    t = __builtin_amdgcn_update_dpp(t, __float_as_int(x), 0x150 + 8 + S, 0xf, 0xc, false);
+    return __int_as_float(t);
+}
+
+// The leaf chain on registers: lane (rg = lane >> 3, sub = lane & 7) holds columns sub + 8 k of row rg in x[k].
+// FAST: Markstein divisions (exact unless a significand is all ones, which the caller has excluded); otherwise true
+// divides / table look-ups.  Step i (obq.py:106-118): q = quantizer(x_i); err = float64(x_i - q) / U[i][i];
+// x_c <- float32(float64(x_c) - err * U[i][c]) for the columns c > i, product and difference rounded separately.
+template <int NSTEP, bool FAST>
+__device__ __forceinline__ void leaf_chain8(const LeafTables8 &lt, int sub, float (&x)[4], float (&q)[4], float (&e)[4], const Grid g,
+                                            float inv_step) {
+    constexpr int NK = NSTEP / 8;
+    const double2_t *urow = reinterpret_cast<const double2_t *>(&lt.u[0][4 * sub]);  // + 16 doubles per row of U
+    double2_t ulo = urow[0], uhi = NK > 2 ? urow[1] : (double2_t){0.0, 0.0};
+    double2_t dr = *reinterpret_cast<const double2_t *>(&lt.udr[0][0]);
+    static_for<0, NSTEP>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int kk = i >> 3, s = i & 7;
+        const double u[4] = {ulo[0], ulo[1], uhi[0], uhi[1]};
+        const double uii = dr[0], rii = dr[1];
+        if constexpr (i + 1 < NSTEP) {
+            // the next step's operands are read before this step starts; only the pairs it still updates
+            constexpr int first = ((i + 1) >> 3) + (((i + 1) & 7) == 7 ? 1 : 0);  // its first live register
+            if constexpr (first < 2) ulo = urow[16 * (i + 1)];
+            if constexpr (first < NK && NK > 2) uhi = urow[16 * (i + 1) + 1];
+            dr = *reinterpret_cast<const double2_t *>(&lt.udr[i + 1][0]);
+        }
+        if constexpr (NK == 4) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
+        else asm volatile("" : "+v"(x[0]), "+v"(x[1])::"memory");
+        // column i of each of the wave's eight rows, broadcast inside its 8-lane group; every lane recomputes the
+        // column's error for its own row.  Nothing is kept per step (a lane's own q and e come after the loop).
+        const float xi = bcast8<s>(x[kk]);
+        double err;
+        if (FAST) {
+            const float qv = grid_value_fast_med3(xi, g, inv_step);
+            const double d = (double)(xi - qv);
+            const double qq = d * rii;
+            const double rem = __builtin_fma(-uii, qq, d);
+            err = __builtin_fma(rem, rii, qq);
+        } else {
+            err = (double)(xi - cb_value(xi, g)) / uii;
+        }
+#pragma unroll
+        for (int k = kk; k < NK; ++k) {
+            if (k == kk && s == 7) continue;  // the last column of register kk: nothing right of it in that register
+            x[k] = (float)((double)x[k] - err * u[k]);
+        }
+    });
+    // A lane's own columns are final once their step has passed: the block of U is zero on and below the diagonal, so the
+    // later steps of their register subtract err * 0.  Their q and e are the same expressions on the same value as in the
+    // step that broadcast it: computed once here.
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const double2_t d = *reinterpret_cast<const double2_t *>(&lt.udr[sub + 8 * k][0]);
+        const float xv = x[k];
+        float qv;
+        double err;
+        if (FAST) {
+            qv = grid_value_fast_med3(xv, g, inv_step);
+            const double dd = (double)(xv - qv);
+            const double qq = dd * d[1];
+            const double rem = __builtin_fma(-d[0], qq, dd);
+            err = __builtin_fma(rem, d[1], qq);
+        } else {
+            qv = cb_value(xv, g);
+            err = (double)(xv - qv) / d[0];
+        }
+        q[k] = qv;
+        e[k] = (float)err;
+    }
+}
+
 template <int SETS>
 __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, float *__restrict__ Eg,
                                                       const double *__restrict__ U, int R, int n, int w0, int w1,
@@ -163,7 +246,9 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
     // The oldest wave of a SIMD issues first, so a helper (waves 4-7) would only get the slots its chain wave leaves; in
     // the first periods the helpers are the longer side, and with raised priority the two meet in the middle (73.0 ->
     // 70.0 us per launch; the same priority on the chain waves instead changes nothing, they are the oldest already).
-    if (helper) __builtin_amdgcn_s_setprio(3);
+    // (prof bits 64 / 128, measurement only: no helper priority / the chain waves raised instead)
+    if (helper && !(prof & (64 | 128))) __builtin_amdgcn_s_setprio(3);
+    if (!helper && (prof & 128)) __builtin_amdgcn_s_setprio(3);
     const int ht = role_wave * 64 + lane;                   // thread index within the role, 0-255
     const int r0 = blockIdx.x * RBX;
     U += (size_t)(r0 / rpl) * n * n;  // a batch of layers stacked by rows: rows [b rpl, (b + 1) rpl) use factor b
@@ -303,8 +388,36 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                     local_update(sm.sblk[SETS == 1 ? par : 0], P.s, P.w1, a, w);
                 }
                 lap(2);
-                const LeafTables &lt = sm.lt[par][lf];
                 const bool fast = fast_ok && (sm.odd[par][lf][0] | sm.odd[par][lf][1] | sm.odd[par][lf][2] | sm.odd[par][lf][3]) == 0;
+                if constexpr (SETS == 2) {
+                    // EIGHT rows per chain wave, 8 lanes x 4 columns per lane (leaf_chain8): one quantizer instruction stream
+                    // for both sets of four rows instead of two interleaved ones -- the chain is bound by instruction issue
+                    const auto &lt = sm.lt[par][lf];
+                    const int sub = lane & 7, g8 = lane >> 3;
+                    const int lrow = RB * (g8 >> 2) + 4 * role_wave + (g8 & 3);  // this lane's row: the two sets of local_update
+                    const bool live = r0 + lrow < R;
+                    float x[4], qv[4], ev[4];
+                    bool m[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        m[k] = sub + 8 * k < w;
+                        x[k] = m[k] ? sm.q[lrow][a - w0 + sub + 8 * k] : 0.0f;
+                        qv[k] = ev[k] = 0.0f;
+                    }
+                    if (!fast) leaf_chain8<32, false>(lt, sub, x, qv, ev, g, inv_step);
+                    else if (w <= 16) leaf_chain8<16, true>(lt, sub, x, qv, ev, g, inv_step);
+                    else leaf_chain8<32, true>(lt, sub, x, qv, ev, g, inv_step);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (m[k]) {
+                            const int col = a + sub + 8 * k;
+                            sm.q[lrow][col - w0] = qv[k];
+                            sm.e[lrow][ring(col)] = ev[k];
+                            if (live) Eg[(size_t)(r0 + lrow) * n + col] = ev[k];
+                        }
+                    }
+                } else {
+                const auto &lt = sm.lt[par][lf];
                 const bool m0 = c16 < w, m1 = c16 + 16 < w;
                 float x0[SETS], x1[SETS], q0[SETS], q1[SETS], e0[SETS], e1[SETS];
 #pragma unroll
@@ -328,6 +441,7 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                         sm.e[row[st]][ring(a + 16 + c16)] = e1[st];
                         if (row_live[st]) Eg[(size_t)(r0 + row[st]) * n + a + 16 + c16] = e1[st];
                     }
+                }
                 }
                 lap(1);
             }
@@ -361,7 +475,7 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
             const Period P = tab.p[p];
 #pragma unroll
             for (int lf = 0; lf < 2; ++lf) {
-                LeafTables &lt = sm.lt[p & 1][lf];
+                auto &lt = sm.lt[p & 1][lf];
                 const int w = lf ? P.w2 : P.w1;
                 // a thread meets at most one diagonal slot (e = 33 i) per leaf: one division, not four
                 double dgv = 1.0;
@@ -370,7 +484,7 @@ __global__ __launch_bounds__(512) void k_gptq_window2(float *__restrict__ Qp, fl
                 for (int h = 0; h < 4; ++h) {
                     const int e = ht + 256 * h, i = e >> 5, j = e & 31;
                     const bool in = i < w && j < w;
-                    lt.u[i][j] = (in && j > i) ? pu[lf][h] : 0.0;
+                    lt.u[i][SETS == 1 ? j : (j & 7) * 4 + (j >> 3)] = (in && j > i) ? pu[lf][h] : 0.0;
                     if (i == j) {
                         dgv = in ? pu[lf][h] : 1.0;
                         di = i;

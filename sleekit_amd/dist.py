@@ -197,7 +197,9 @@ class HipBackend:
         eng = self.engine
         W = layer["W"][lo:hi].contiguous()
         sc = layer["scale"][lo:hi].contiguous() if layer.get("scale") is not None else None
-        res = eng.quantize_layer(W, layer["H"], self.quantizer, sc, self.act_order, self.damp, self.moves, factor=factor[:3])
+        # (lookahead = "alone on the GPU": with overlapping streams the loop takes the window kernel's least-chip-time form)
+        res = eng.quantize_layer(W, layer["H"], self.quantizer, sc, self.act_order, self.damp, self.moves, factor=factor[:3],
+                                 lookahead=not self.overlap)
         err = None
         if self.with_error and len(factor) > 3:  # the verdict on H's symmetry came with the factor
             err = eng.row_errors_batch(W[None], res.Q[None], [layer["H"]], factor[3])[0]

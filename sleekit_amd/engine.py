@@ -138,8 +138,9 @@ def factorize_order_only(H, n, mode, miss=None):
     return order, None, None
 
 
-def run_loop(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=True, want_E=False, unscale=False):
-    """The column-sequential loop on device tensors. Returns (Q, idx, E); `unscale`: Q comes back de-scaled."""
+def run_loop(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=True, want_E=False, unscale=False, latency=False):
+    """The column-sequential loop on device tensors. Returns (Q, idx, E); `unscale`: Q comes back de-scaled; `latency`:
+    this layer is alone on the GPU (SLK_LOOP_LATENCY: 16-row window workgroups; same results)."""
     R, n = W.shape
     levels, lo, hi, table = cb_abi
     ws, ws_bytes = dev.workspace(R, n)
@@ -149,7 +150,7 @@ def run_loop(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=True, w
     _lib.check(
         _lib.lib.slk_gptq_quantize(
             dev.ptr(W), dev.ptr(scale), dev.ptr(order), dev.ptr(U), R, n, levels, lo, hi, dev.ptr(table), int(min_block),
-            int(num_blocks), 1 if unscale else 0, dev.ptr(Q), dev.ptr(idx), dev.ptr(E), dev.ptr(ws), ws_bytes,
+            int(num_blocks), (1 if unscale else 0) | (2 if latency else 0), dev.ptr(Q), dev.ptr(idx), dev.ptr(E), dev.ptr(ws), ws_bytes,
             dev.stream_handle(),
         )
     )
@@ -281,7 +282,8 @@ def quantize_layer(
     LayerResult whose Q is de-scaled when `scale` is given and `unscale` is true
     (sleekit/scaling.py:58-81), else the codebook values in the scaled domain
     (sleekit/obq.py:169-217).  want_ls_trace: res.ls_trace = the local search's moves (slk_local_search).
-    lookahead: see factorize (one layer at a time: on).
+    lookahead: this layer is alone on the GPU (the default of this single-layer API; sleekit_amd.dist passes False): the
+    factorisation looks ahead (see factorize) and the loop's window kernel takes 16-row workgroups (SLK_LOOP_LATENCY).
     """
     assert W.ndim == 2
     assert H.ndim == 2
@@ -309,7 +311,7 @@ def quantize_layer(
 
     # without local search the loop's last kernel de-scales on the way out (one pass over Q less)
     fused = scale is not None and unscale and nb_ls_moves == 0 and loop_scale is not None
-    res.Q, res.idx, _ = run_loop(Ws, loop_scale, res.order, res.U, cb_abi, min_block_size, num_blocks, want_idx, unscale=fused)
+    res.Q, res.idx, _ = run_loop(Ws, loop_scale, res.order, res.U, cb_abi, min_block_size, num_blocks, want_idx, unscale=fused, latency=lookahead)
     if nb_ls_moves > 0:
         res.ls_trace = local_search(Ws, res.Q, H, cb_abi, nb_ls_moves, res.idx, want_trace=want_ls_trace)
     if scale is not None and unscale and not fused:

@@ -336,11 +336,13 @@ def test_window_kernels_agree(amd, n, odd_diagonal, slkopt):
     cb = amd.codebook.UniformCodebook(8, -1, 1)
     out = []
     for variant in ("rows16", "rows32", "general"):
+        # rows16: four rows per chain wave (16 lanes x 2 columns); rows32: EIGHT rows per chain wave (8 lanes x 4 columns,
+        # one quantizer stream for them) and single U buffers; general: 16-row MFMA, barrier per op
         if variant == "general":
             slkopt.setenv("SLK_NO_WINDOW2", "1")
         else:
             slkopt.delenv("SLK_NO_WINDOW2", raising=False)
-            slkopt.setenv("SLK_WINDOW_ROWS", variant[4:])  # 32: two interleaved sets of rows per chain wave, single U buffers
+            slkopt.setenv("SLK_WINDOW_ROWS", variant[4:])
         Q, E = W.copy(), np.zeros_like(W)
         amd.obq._quantize_opt_block(Q, E, U, cb, 32, 8)
         out.append((Q, E))
@@ -1003,11 +1005,11 @@ def test_batch_entry_points(amd, B, R, n, levels):
         for b in range(B):
             q1, i1, _ = eng.run_loop(W[b], None if scale is None else scale[b], facs[b][0], facs[b][1], abi, 32, 8, unscale=unscale)
             assert torch.equal(Q[b], q1) and torch.equal(idx[b], i1), (b, unscale)
-        # the 32-row window workgroups (two row sets per chain wave; a tile of 32 rows never straddles two layers of a
-        # stack: rows per layer are a multiple of 64): the same bits, uniform and table codebooks alike
-        with amd.lib.option("window_rows", 32):
-            Q32, idx32 = eng.run_loop_batch(W, scale, order, U, abi, 32, 8, unscale=unscale)
-        assert torch.equal(Q32, Q) and torch.equal(idx32, idx), unscale
+        # the 16-row window workgroups against the default 32-row ones (eight rows per chain wave; a tile of 32 rows never
+        # straddles two layers of a stack: rows per layer are a multiple of 64): the same bits, uniform and table codebooks alike
+        with amd.lib.option("window_rows", 16):
+            Q16, idx16 = eng.run_loop_batch(W, scale, order, U, abi, 32, 8, unscale=unscale)
+        assert torch.equal(Q16, Q) and torch.equal(idx16, idx), unscale
     if R % 128:  # 64-row shards: the loop batches (tiles of 64), the error entry needs 128
         with pytest.raises(RuntimeError, match="multiple of 128"):
             eng.row_errors_batch(W, W, Hs)

@@ -18,7 +18,7 @@ reps = 3
 for rep in range(reps):
     engine.run_loop(W, None, order, U, cb, 32, 8)
 _lib.check(_lib.lib.slk_probe_window_cycles(buf, 1))
-names2 = {0: "prologue (wave 0 / wave 4 mixed)", 1: "chain: leaves incl. loads/stores", 2: "chain: local updates", 3: "chain: barrier wait", 4: "helper: block staging issue", 10: "helper: table fetch", 11: "helper: rest of tile", 5: "helper: deferred update", 6: "helper: table write", 7: "helper: barrier wait", 9: "kernel total"}
+names2 = {0: "prologue (chain wave 0 / first helper)", 1: "chain: leaves incl. loads/stores", 2: "chain: local updates", 3: "chain: barrier wait", 4: "helper: block staging issue", 10: "helper: table fetch", 11: "helper: rest of tile", 5: "helper: deferred update", 6: "helper: table write", 7: "helper: barrier wait", 9: "kernel total"}
 names = {0: "leaf chain (wave 0)", 1: "stage + barrier before leaf", 2: "barrier after leaf (wave 0)", 3: "urgent update (wave 0)",
          4: "barrier after update", 5: "deferred update (wave 4)", 6: "wave 4: barrier after its part", 7: "tile load", 8: "tile store", 9: "kernel total", 10: "update pass set-up (wave 0)", 11: "aux 11", 12: "aux 12"}
 launches = reps * 8
@@ -28,6 +28,6 @@ for k, name in names.items():
     print(f"  {name:<32s} {buf[k] / launches / 2400.0:8.2f} us per window launch")
 
 if not os.environ.get("SLK_NO_WINDOW2"):
-    print("  busy us per period (chain wave 0 | helper wave 2):")
+    print("  busy us per period (chain wave 0 | first helper wave):")
     for p in range(8):
         print(f"    period {p}: {buf[16 + p] / launches / 2400.0:6.2f} | {buf[48 + p] / launches / 2400.0:6.2f}")

@@ -320,6 +320,11 @@ class Leg:
             for key in ("traffic_source", "peak_kind", "share_of_kernel_time", "algorithmic_per_launch", "launches"):
                 roofline.pop(key, None)
         roofline["steps_with_events_ms"] = round(1e3 * t_prof / n_steps, 3)
+        # how full the chip was: the launches' chip time (duration x share of the 256 CUs a launch can occupy) over the wall
+        # time of the same steps -- above 1 when kernels of several streams share CUs, far below 1 when the step is a chain
+        # of narrow or short launches
+        roofline["chip_time_over_wall"] = round(sum(k["chip_ms"] for k in table) / (1e3 * t_prof), 3)
+        roofline["kernel_time_over_wall"] = round(sum(k["total_ms"] for k in table) / (1e3 * t_prof), 3)
 
         def frac_of(k):
             kd = KERNEL_DTYPE.get(k["kernel"])

@@ -28,8 +28,9 @@ constexpr int TP = 66;  // pitch of the 64 x 64 LDS tiles: MFMA operand reads wa
 
 struct PanelSmem {
     double t[PANEL][TP];    // diagonal tile -> L11 (lower)
-    double x[PANEL][TP];    // inv(L11)
-    double a21[PANEL][TP];  // this workgroup's tile of A21, staged while the diagonal tile is being factored
+    double x[PANEL][TP];    // inv(L11); before the factorisation starts: the previous panel's L of the diagonal tile's rows
+    double a21[PANEL][TP];  // this workgroup's tile of A21
+    double lb[PANEL][TP];   // the previous panel's L of this workgroup's rows
     double rdiag[PANEL];    // 1 / L11[j][j]
 };
 
@@ -97,31 +98,110 @@ __device__ __forceinline__ double4_t blk_mma_a_reg(const double *a, double4_t s,
 //   inverse   off-diagonal blocks X[rb, cb] = -X[rb, rb] * sum_k L[rb, k] X[k, cb] level by level;
 //             the inner sum stays in registers: an accumulator tile is already the next B operand.
 // Two barriers per strip, three for the inverse.
-__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int ld, int k0,
+__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int ld, int k0, int kprev, int below, int rest_cols,
                                                     double *__restrict__ X, int *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    PanelSmem &sm = *reinterpret_cast<PanelSmem *>(smem_raw);
     // (blockIdx.z: the layer of a batched factorisation -- square matrices of one size, one after the other)
     A += (size_t)blockIdx.z * ld * ld;
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x >= below) {
+        // ---- part B: what is left of the PREVIOUS panel's update inside this outer block -- the tile columns right of this
+        //      panel, C[bi][bj] -= L[bi][kprev ...] L[bj][kprev ...]^T (K = 64), which only the panels after this one read.
+        //      (It used to be a launch of its own between two panels, k_syrk_tiles over all the block's columns: the part this
+        //      panel needs is now its prologue below, the rest rides along here.)
+        Tile64Smem &ts = *reinterpret_cast<Tile64Smem *>(smem_raw);
+        const int nt = ld / TILE, tj0 = k0 / TILE + 1;
+        int idx = (int)blockIdx.x - below, bj = tj0;
+        for (int c = 0; c < rest_cols; ++c, ++bj) {
+            const int count = nt - bj;
+            if (idx < count) break;
+            idx -= count;
+        }
+        const int bi = bj + idx;
+        if (bj >= tj0 + rest_cols || bi >= nt) return;
+        Acc64 acc;
+        acc.zero();
+        const double *pa = A + ((size_t)bi * TILE + (t >> 2)) * ld + (t & 3) * 8;
+        const double *pb = A + ((size_t)bj * TILE + (t >> 2)) * ld + (t & 3) * 8;
+        double *pc = A + (size_t)bi * TILE * ld + (size_t)bj * TILE;
+        Acc64 old;  // fetched NOW: its trip to memory hides behind the products
+        tile64_map(old, [&](int r, int c) { return pc[(size_t)r * ld + c]; });
+        tile64_mac<false>(
+            acc, ts, kprev, kprev + PANEL, [&](int k, double(&v)[8]) { load8d<true>(pa + k, v); },
+            [&](int k, double(&v)[8]) { load8d<true>(pb + k, v); });
+        tile64_foreach2(old, acc, [&](int r, int c, double o, double v) { pc[(size_t)r * ld + c] = o - v; });
+        return;
+    }
+    PanelSmem &sm = *reinterpret_cast<PanelSmem *>(smem_raw);
     X += (size_t)blockIdx.z * ld * ld;
     info += blockIdx.z;
-    const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
+    const bool has_prev = kprev >= 0, has_rows = blockIdx.x > 0;
 
-    // this workgroup's tile of A21, fetched NOW: it does not depend on the factorisation, and loaded only when the
-    // final product starts its trip to memory (~1.5 us) would sit on the critical path of every panel
-    double a21[2][8];
-    if (blockIdx.x > 0) {
-        const double *pa = A + (size_t)(k0 + PANEL * blockIdx.x + (t >> 2)) * ld + k0 + (t & 3) * 8;
-        load8d<true>(pa, a21[0]);
-        load8d<true>(pa + 32, a21[1]);
-    }
-    for (int e = t; e < PANEL * PANEL; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        sm.t[r][c] = (c <= r) ? A[(size_t)(k0 + r) * ld + k0 + c] : 0.0;
-        sm.x[r][c] = 0.0;
+    // Everything this workgroup reads is fetched NOW, in one round trip: the diagonal tile, its own tile of A21 and -- when
+    // a panel of this outer block came before -- that panel's L for the diagonal tile's rows and for its own rows.
+    {
+        const int r = t >> 2, c8 = (t & 3) * 16;  // a thread carries 16 consecutive doubles of one row of every tile
+        const double *pd = A + (size_t)(k0 + r) * ld + k0 + c8;
+        const double *pt = A + (size_t)(k0 + PANEL * blockIdx.x + r) * ld + k0 + c8;
+        double vd[16], vt[16], vk[16], vb[16];
+        load8d<true>(pd, *reinterpret_cast<double(*)[8]>(&vd[0]));
+        load8d<true>(pd + 8, *reinterpret_cast<double(*)[8]>(&vd[8]));
+        if (has_rows) {
+            load8d<true>(pt, *reinterpret_cast<double(*)[8]>(&vt[0]));
+            load8d<true>(pt + 8, *reinterpret_cast<double(*)[8]>(&vt[8]));
+        }
+        if (has_prev) {
+            const double *pk = A + (size_t)(k0 + r) * ld + kprev + c8;
+            load8d<true>(pk, *reinterpret_cast<double(*)[8]>(&vk[0]));
+            load8d<true>(pk + 8, *reinterpret_cast<double(*)[8]>(&vk[8]));
+            if (has_rows) {
+                const double *pl = A + (size_t)(k0 + PANEL * blockIdx.x + r) * ld + kprev + c8;
+                load8d<true>(pl, *reinterpret_cast<double(*)[8]>(&vb[0]));
+                load8d<true>(pl + 8, *reinterpret_cast<double(*)[8]>(&vb[8]));
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const int c = c8 + e;
+            // without an earlier panel the upper triangle is cleared (never read); with one the whole tile takes the update
+            *reinterpret_cast<double2_t *>(&sm.t[r][c]) = (double2_t){(has_prev || c <= r) ? vd[e] : 0.0, (has_prev || c + 1 <= r) ? vd[e + 1] : 0.0};
+            if (has_rows) *reinterpret_cast<double2_t *>(&sm.a21[r][c]) = (double2_t){vt[e], vt[e + 1]};
+            if (has_prev) {
+                *reinterpret_cast<double2_t *>(&sm.x[r][c]) = (double2_t){vk[e], vk[e + 1]};
+                if (has_rows) *reinterpret_cast<double2_t *>(&sm.lb[r][c]) = (double2_t){vb[e], vb[e + 1]};
+            } else {
+                *reinterpret_cast<double2_t *>(&sm.x[r][c]) = (double2_t){0.0, 0.0};
+            }
+        }
     }
     __syncthreads();
+
+    // ---- prologue (has_prev): the previous panel's update of this panel's tile column, which used to be part of a launch
+    //      of its own (k_syrk_tiles).  C -= L_rows L_diag^T, K = 64, accumulated from zero over ascending k and subtracted
+    //      once -- the same chain of fused multiply-adds and the same single rounding of the difference as that kernel's
+    //      (tile64_mac + `old - acc`), so the factor is unchanged bit for bit.
+    //      Diagonal tile: the ten 16 x 16 blocks on and below its diagonal, all four waves, before the pivots can start.
+    //      Own tile (16 blocks): waves 1 - 3, in the shadow of the first strip's pivot chain.
+    auto block_syrk = [&](double (*c)[TP], const double (*a)[TP], int rb, int cb) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) acc = blk_mma_abt(&a[16 * rb][16 * kq], &sm.x[16 * cb][16 * kq], acc, 1.0, lane);
+        double *cp = &c[16 * rb][16 * cb];
+        double4_t o = blk_load_d(cp, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = o[r] - acc[r];
+        blk_store_d(cp, lane, o);
+    };
+    if (has_prev) {
+        int i = 0;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb <= rb; ++cb, ++i)
+                if ((i & 3) == wave) block_syrk(sm.t, sm.x, rb, cb);
+        __syncthreads();
+    }
 
     // inverse of the 16 x 16 diagonal block of strip kb: lane c < 16 owns column c of X[kb, kb] (wave 3 runs it while
     // wave 0 is in the NEXT strip's chain: the block and its reciprocal diagonal are final by then, and nothing else
@@ -178,9 +258,15 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
 #pragma unroll
                 for (int c = 0; c < 16; ++c) sm.t[row][c0 + c] = (c0 + c <= row) ? a[c] : 0.0;
             }
+        } else if (kb == 0) {
+            if (has_prev && has_rows) {  // the own tile's update (see the prologue), 16 blocks over waves 1 - 3
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i % 3 == wave - 1) block_syrk(sm.a21, sm.lb, i >> 2, i & 3);
+            }
         } else if (wave == 3) {
-            if (kb > 0) diag_inverse(kb - 1);
-        } else if (kb > 0) {
+            diag_inverse(kb - 1);
+        } else {
             // deferred updates of the strip before: the blocks that strip's successor did not need (cb > kb), done while
             // wave 0 is in this strip's chain.  Every block belongs to one wave (cb odd: wave 1, even: wave 2 -- and
             // (3, 3) to wave 1), which applies the strips' updates to it in order.
@@ -191,12 +277,8 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
                     if (block_owner(rb, cb) == wave) block_update(rb, cb, kb - 1);
         }
         __syncthreads();
-        if (kb == 0 && blockIdx.x > 0) {  // the tile of A21 has landed by now: registers -> LDS, row-major like t and x
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int e = 0; e < 8; e += 2)
-                    *reinterpret_cast<double2_t *>(&sm.a21[t >> 2][32 * h + (t & 3) * 8 + e]) = (double2_t){a21[h][e], a21[h][e + 1]};
+        if (kb == 0 && has_prev) {  // the previous panel's L has served: x is the inverse's from here on (zero above the diagonal)
+            for (int e = t; e < PANEL * PANEL; e += 256) sm.x[e >> 6][e & 63] = 0.0;
         }
         // ---- the blocks the NEXT strip reads, (rb, kb + 1): one per wave 1 .. 3, then wave 0 goes on
         if (kb < 3) {
@@ -393,18 +475,20 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
         const int K1 = K0 + OUTER < ld ? K0 + OUTER : ld;
         for (int k0 = K0; k0 < K1; k0 += PANEL) {
             const int below = (ld - k0) / PANEL;  // tiles from the diagonal tile down
-            // potf2 + inverse of the 64-tile (2/3 * 64^3) and the triangular product below it
-            SLK_RUN_W("chol_panel", Bd * (2.0 / 3.0 * 64 * 64 * 64 + (double)(below - 1) * 64 * 64 * 64), Bd * 16.0 * below * 64 * 64,
-                      below * batch, s, k_chol_panel<<<dim3(below, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, k0, X, info));
-            // inner update: columns of this outer block to the right of the panel
-            const int tj0 = k0 / TILE + 1, tj1 = K1 / TILE;
-            if (tj1 > tj0) {
-                dim3 grid(tj1 - tj0, nt - tj0, B);
-                double tiles = 0;
-                for (int bj = tj0; bj < tj1; ++bj) tiles += nt - bj;
-                SLK_RUN_W("chol_syrk_inner", Bd * tiles * 2.0 * 64 * 64 * PANEL, Bd * (8.0 * (ld - k0) * PANEL + tiles * 16.0 * 64 * 64),
-                          tiles * batch, s, k_syrk_tiles<<<grid, 256, 0, s>>>(A, ld, tj0, tj0, k0, k0 + PANEL));
-            }
+            // ONE launch per panel: [the previous panel's update of this tile column (prologue of every workgroup); potf2 +
+            // inverse of the diagonal tile; the triangular product below it] in `below` workgroups, and in the same grid what
+            // is left of the previous panel's update inside this outer block: the tile columns right of this panel (`rest`).
+            // (Until round 3 the whole inner update was a launch of its own between two panels: 112 dependent launches per
+            // 4096-column factor, now 64 + 16.)
+            const int kprev = k0 > K0 ? k0 - PANEL : -1;
+            const int rest_cols = kprev >= 0 ? (K1 - k0) / PANEL - 1 : 0;
+            int rest = 0;
+            for (int c = 0; c < rest_cols; ++c) rest += nt - (k0 / TILE + 1 + c);
+            const double prologue = kprev >= 0 ? (double)below * 2.0 * 64 * 64 * 64 + (double)below * 2.0 * 64 * 64 * 64 : 0.0;  // own + diagonal tile
+            SLK_RUN_W("chol_panel",
+                      Bd * (2.0 / 3.0 * 64 * 64 * 64 + (double)(below - 1) * 64 * 64 * 64 + prologue + (double)rest * 2.0 * 64 * 64 * PANEL),
+                      Bd * (16.0 * below * 64 * 64 + (double)rest * 16.0 * 64 * 64), (below + rest) * batch, s,
+                      k_chol_panel<<<dim3(below + rest, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, k0, kprev, below, rest_cols, X, info));
         }
         const int t0 = K1 / TILE;
         if (nt > t0) {

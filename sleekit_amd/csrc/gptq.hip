@@ -915,7 +915,10 @@ extern "C" int slk_gptq_quantize_batch(const float *W, const float *scale, const
     // 5040 -> 5180 Mweights/s, OPT-125M 5350 -> 5700, OPT-350M 4430 -> 4650, BLOOM-560M 3620 -> 3860) -- the default.  16
     // rows (four per chain wave) are faster for ONE layer alone: callers ask with SLK_LOOP_LATENCY (the single-layer API
     // does).  slk_set_option("window_rows", 16 | 32) forces either.
-    const int window_rows = opt(OPT_WINDOW_ROWS) == 16 || opt(OPT_WINDOW_ROWS) == 32 ? opt(OPT_WINDOW_ROWS) : ((flags & SLK_LOOP_LATENCY) ? 16 : 32);
+    // (fewer than 2048 rows -- the row shards of small layers on several ranks -- leave most CUs idle either way: what
+    // counts then is the length of the launch chain, 16 rows again: one rank of 8 on OPT-125M 14.0 -> 12.6 ms per step)
+    const int window_rows = opt(OPT_WINDOW_ROWS) == 16 || opt(OPT_WINDOW_ROWS) == 32 ? opt(OPT_WINDOW_ROWS)
+                                                                                     : (((flags & SLK_LOOP_LATENCY) || R < 2048) ? 16 : 32);
     const bool periods_ok = n % 2 == 0 && n <= 16384 && (uintptr_t)U % 16 == 0 && !opt(OPT_NO_WINDOW2) && (dbg & ~(24 | 64 | 128)) == 0;
 
     // rows staged through LDS when they fit and 16-byte accesses line up

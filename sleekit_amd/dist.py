@@ -170,6 +170,34 @@ class HipBackend:
             factor = factor + (eng.symmetry_flag(H),)
         return factor
 
+    def factorize_many(self, layers):
+        """The factors of several layers of ONE width in launches that cover them all (engine.factorize_batch: bit-equal to
+        factorize, one by one): what a rank owes to a group of rounds of small layers."""
+        eng = self.engine
+        n = layers[0]["H"].shape[0]
+        mode = eng.order_mode_code(self.act_order)
+        if mode not in (0, 1) or any(lay["H"].shape[0] != n for lay in layers) or len(layers) > 64:
+            return [self.factorize(lay) for lay in layers]
+        order, U, info = eng.factorize_batch([lay["H"] for lay in layers], n, self.damp, mode)
+        out = []
+        for b, lay in enumerate(layers):
+            fac = (order[b], U[b], info[b:b + 1])
+            if self.with_error:
+                fac = fac + (eng.symmetry_flag(lay["H"]),)
+            out.append(fac)
+        return out
+
+    group_rows = 8192  # stacked (padded) rows a loop batch of small shards may reach
+
+    def group_limit(self, layer, rows):
+        """How many layers of this shape, `rows` of them on this rank, go through the loop as one batch (0: round by round).
+        Small layers only: their shards are chains of short launches (wants_local_batch), and the stacked factors must fit."""
+        if rows <= 0 or not self.wants_local_batch(layer):
+            return 0
+        n = layer["H"].shape[0]
+        padded = (rows + 127) // 128 * 128
+        return int(min(64, self.group_rows // padded, (1 << 31) // (8 * n * n)))
+
     def note_statuses(self, infos, layers, defer=False):
         """The status words of the layers' factorisations (0, or 1 + the failing pivot), one per layer of the stream:
         LinAlgError like the reference's np.linalg.cholesky (sleekit/obq.py:49-50), naming the layer -- now (ONE read
@@ -461,6 +489,27 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
     return out
 
 
+def _group_rounds(rounds, layers, backend, rank, size):
+    """Consecutive rounds of one shape joined into groups of at most backend.group_limit(layer, shard rows) layers (the
+    loop batch the backend wants for such shards); without that hook, or for big layers (limit below two rounds), every
+    round is a group of its own."""
+    limit_of = getattr(backend, "group_limit", None)
+    groups, key_now, count, limit = [], None, 0, 0
+    for g, members in enumerate(rounds):
+        first = layers[members[0]]
+        same = len({(tuple(layers[l]["W"].shape), layers[l].get("scale") is not None) for l in members}) == 1
+        key = (tuple(first["W"].shape), first.get("scale") is not None) if same else None
+        if limit_of is not None and key is not None and key == key_now and count + len(members) <= limit:
+            groups[-1].append(g)
+            count += len(members)
+            continue
+        groups.append([g])
+        key_now, count = key, len(members)
+        lo, hi = row_range(first["W"].shape[0], rank, size)
+        limit = int(limit_of(first, hi - lo)) if (limit_of is not None and key is not None) else 0
+    return groups
+
+
 def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
     """Quantize `layers` (list of dicts with W (R, n), H (n, n), optional scale (R,)) across the ranks.
 
@@ -508,68 +557,105 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
     def on(stream):
         return torch.cuda.stream(stream) if stream is not None else _NullCtx()
 
+    # Rounds of SMALL layers are taken in GROUPS (the backend says how many layers it wants in one loop batch:
+    # group_limit): a rank factors all its layers of a group in one batched factorisation, the group's payloads cross in ONE
+    # all-gather (a slot per round in every rank's buffer) and its row shards go through the loop as ONE stack.  The shards
+    # of a small layer on several ranks are a chain of short launches whatever their height (one rank of 8 on OPT-125M: 10
+    # rounds x 15 loop launches and 9 factorisations x 45 launches per step, as long as the whole model on one GPU);
+    # groups make it 3 x 15 and 3 x 45.  A group of one round is the plain scheme.
+    groups = _group_rounds(rounds, layers, backend, rank, size) if exchange else [[g] for g in range(n_rounds)]
+    slot = {}  # layer -> its round's slot in the group's buffers
+    for members_g in groups:
+        for j, g in enumerate(members_g):
+            for l in rounds[g]:
+                slot[l] = j
+
     # 1. every rank factors the layers it is the root of (concurrently across ranks), in processing order; the
     #    factorisations are latency-bound chains, so consecutive ones alternate between streams
     #    (the rotation carries on from the previous call: with one layer per rank and call -- a round of G
     #    layers on G ranks -- consecutive calls would otherwise queue on the same stream, one chain behind the other)
-    mine = [l for members in rounds for l in members if root[l] == rank]
+    jobs = []  # lists of layers factored together
+    for members_g in groups:
+        own = [l for g in members_g for l in rounds[g] if root[l] == rank]
+        if len(members_g) > 1 and len(own) > 1 and hasattr(backend, "factorize_many"):
+            jobs.append(own)
+        else:
+            jobs.extend([l] for l in own)
     first = getattr(backend, "_factor_rotation", 0) if side else 0
     if side:
-        backend._factor_rotation = (first + len(mine)) % len(fstreams)
+        backend._factor_rotation = (first + len(jobs)) % len(fstreams)
     stream_of = {}  # layer -> the stream its factorisation went to
-    for k, l in enumerate(mine):
+    for k, job in enumerate(jobs):
         fs = fstreams[(first + k) % len(fstreams)] if side else None
-        stream_of[l] = fs
         if side and k < len(fstreams):
             fs.wait_stream(here)
         with on(fs):
-            factors[l] = backend.factorize(layers[l])
+            made = backend.factorize_many([layers[l] for l in job]) if len(job) > 1 else [backend.factorize(layers[job[0]])]
+            ev = None
             if side:
-                ready[l] = torch.cuda.Event()
-                ready[l].record(fs)
-    # 2. one asynchronous all-gather per round, issued in round order
-    gathered = [None] * n_rounds  # (per-rank payloads, work)
+                ev = torch.cuda.Event()
+                ev.record(fs)
+        for l, fac in zip(job, made):
+            factors[l], ready[l], stream_of[l] = fac, ev, fs
+    # 2. one asynchronous all-gather per group of rounds, issued in order
+    gathered = [None] * len(groups)  # (per-rank buffers, work, words per payload, words per slot)
     keep = []
     if exchange:
         if cstream is not None:
             cstream.wait_stream(here)
         with on(cstream):
-            for g, members in enumerate(rounds):
-                own = [l for l in members if root[l] == rank]  # at most one: a round has at most `size` layers
-                # equal-sized contributions: a round's layers share one shape (padded to the widest otherwise)
+            for gi, members_g in enumerate(groups):
+                members = [l for g in members_g for l in rounds[g]]
+                # equal-sized contributions: a group's layers share one shape (a lone round of mixed shapes: the widest)
                 words = max(backend.payload_words(layers[j]["H"].shape[0]) for j in members)
-                if own:
-                    l = own[0]
-                    if ready[l] is not None:
-                        cstream.wait_event(ready[l])
-                    payload = backend.pack(factors[l], words)
-                    if side:
-                        for t in factors[l]:
-                            t.record_stream(cstream)  # made on a factor stream, read here
-                elif rehearse is not None:
-                    # rehearsal: a real factor of the right shape must stand in for the peers' (a blank one is not a
-                    # permutation + triangle the kernels can run on); made once per shape, outside what is measured
-                    n_ = layers[members[0]]["H"].shape[0]
-                    if (n_, words) not in _rehearsal_payloads:
-                        _rehearsal_payloads[(n_, words)] = backend.pack(backend.factorize(layers[members[0]]), words)
-                    payload = _rehearsal_payloads[(n_, words)]
-                else:  # no layer of this round is this rank's: contribute a blank
-                    dev_ = comm_device if comm_device is not None else layers[0]["H"].device
-                    payload = backend.alloc_payload(words, dev_).zero_()
+                stride = (words + 1) // 2 * 2 if len(members_g) > 1 else words
+                dev_ = comm_device if comm_device is not None else layers[0]["H"].device
+                buffer = None if len(members_g) == 1 else backend.alloc_payload(stride * len(members_g), dev_)
+                for j, g in enumerate(members_g):
+                    own = [l for l in rounds[g] if root[l] == rank]  # at most one: a round has at most `size` layers
+                    if own:
+                        l = own[0]
+                        if ready[l] is not None:
+                            cstream.wait_event(ready[l])
+                        payload = backend.pack(factors[l], words)
+                        if side:
+                            for t in factors[l]:
+                                t.record_stream(cstream)  # made on a factor stream, read here
+                    elif rehearse is not None:
+                        # rehearsal: a real factor of the right shape must stand in for the peers' (a blank one is not a
+                        # permutation + triangle the kernels can run on); made once per shape, outside what is measured
+                        n_ = layers[rounds[g][0]]["H"].shape[0]
+                        if (n_, words) not in _rehearsal_payloads:
+                            _rehearsal_payloads[(n_, words)] = backend.pack(backend.factorize(layers[rounds[g][0]]), words)
+                        payload = _rehearsal_payloads[(n_, words)]
+                    elif buffer is None:  # no layer of this round is this rank's: contribute a blank
+                        payload = backend.alloc_payload(words, dev_).zero_()
+                    else:
+                        payload = None  # (a slot nobody reads)
+                    if buffer is None:
+                        buffer = payload
+                    elif payload is not None:
+                        buffer[j * stride:j * stride + words].copy_(payload)
                 log = getattr(backend, "exchange_log", None)
-                if log is not None and payload.is_cuda:
+                if log is not None and buffer.is_cuda:
                     # measurement (bench.py's pass with events): the comm stream brackets the collective with two events
                     # and waits for it, so that their distance is the exchange itself
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(torch.cuda.current_stream())
-                    gathered[g] = _all_gather_words(payload, size)
-                    gathered[g][1].wait()
+                    parts, work = _all_gather_words(buffer, size)
+                    work.wait()
                     e1.record(torch.cuda.current_stream())
-                    log.append((e0, e1, payload.numel() * payload.element_size() * (size - 1)))
+                    log.append((e0, e1, buffer.numel() * buffer.element_size() * (size - 1)))
                 else:
-                    gathered[g] = _all_gather_words(payload, size)
-                keep.append(payload)
-    # 3. every rank runs its rows of every layer as the factors land, round by round.  A round goes through the
+                    parts, work = _all_gather_words(buffer, size)
+                gathered[gi] = (parts, work, words, stride)
+                keep.append(buffer)
+
+    def payload_of(gi, l):
+        parts, _, words, stride = gathered[gi]
+        return parts[root[l]][slot[l] * stride:slot[l] * stride + words]
+
+    # 3. every rank runs its rows of every layer as the factors land, group by group.  A group goes through the
     #    kernels as ONE batch when the backend can do that (run_round): the shards are R / G rows each, too few to
     #    fill the chip alone.  Otherwise layer by layer, consecutive ones on alternating streams (their leaf chains
     #    are latency-bound).
@@ -579,7 +665,8 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
             st.wait_stream(here)
     # (batched rounds rotate over the loop streams across calls, like the factorisations above)
     batched_rounds = getattr(backend, "_loop_rotation", 0) if side else 0
-    for g, members in enumerate(rounds):
+    for gi, members_g in enumerate(groups):
+        members = [l for g in members_g for l in rounds[g]]
         lo, hi = row_range(layers[members[0]]["W"].shape[0], rank, size)
         if exchange and hasattr(backend, "run_round") and backend.can_batch([layers[l] for l in members], lo, hi):
             ls = lstreams[batched_rounds % len(lstreams)] if side else None
@@ -596,9 +683,9 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
             if side:
                 backend._loop_rotation = batched_rounds % len(lstreams)
             with on(ls):
-                parts, work = gathered[g]
+                parts, work = gathered[gi][:2]
                 work.wait()  # orders the stream behind the transfer; no host block on GPU
-                shards = backend.run_round([layers[l] for l in members], lo, hi, [parts[root[l]] for l in members])
+                shards = backend.run_round([layers[l] for l in members], lo, hi, [payload_of(gi, l) for l in members])
                 if side:
                     for t in parts:
                         t.record_stream(ls)
@@ -610,10 +697,10 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
             ls = lstreams[l % len(lstreams)] if side else None
             with on(ls):
                 if exchange:
-                    parts, work = gathered[g]
+                    parts, work = gathered[gi][:2]
                     work.wait()
                     if factors[l] is None or always_exchange:
-                        factors[l] = backend.unpack(parts[root[l]], layer["H"].shape[0])
+                        factors[l] = backend.unpack(payload_of(gi, l), layer["H"].shape[0])
                 elif ready[l] is not None:
                     ls.wait_event(ready[l])
                 lo, hi = row_range(layer["W"].shape[0], rank, size)
@@ -622,7 +709,7 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
                     for t in factors[l]:
                         t.record_stream(ls)
                     if exchange:
-                        for t in gathered[g][0]:
+                        for t in gathered[gi][0]:
                             t.record_stream(ls)
             shard["info"] = factors[l][2]
             out[l] = shard
@@ -631,7 +718,7 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
             for st in lstreams + fstreams:  # (batched rounds run on factor streams)
                 here.wait_stream(st)
         # tensors made on the side streams are consumed on the caller's stream: keep the allocator honest
-        extra = [(p,) for p in keep] + [tuple(g[0]) for g in gathered if g is not None]
+        extra = [(p,) for p in keep if p is not None] + [tuple(g[0]) for g in gathered if g is not None]
         for f in factors + extra:
             for t in f or ():
                 t.record_stream(here)

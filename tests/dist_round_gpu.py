@@ -53,6 +53,31 @@ def main():
             assert int(sh["info"].item()) == 0
     # bucketed by shape: rounds (0, 3), (1, 4) and the ragged (2, 5) -- padded to whole tiles -- batched; (6) alone
     assert calls["round"] == 4 * 3 and calls["rows"] == 4 * 1, calls
+    # GROUPS of rounds (small layers): 7 layers of one shape on 2 ranks = 4 rounds; the backend wants up to 64 such layers in a
+    # loop batch, so they go as ONE group -- each rank's layers through one batched factorisation, one all-gather with a slot
+    # per round, one stacked loop over all seven -- and every shard still equals the unsharded layer's rows bit for bit
+    small = []
+    for i in range(7):
+        lay = synth.make_layer(100, 192, 900 + i)
+        small.append({k: torch.from_numpy(lay[k]).to(device) for k in ("W", "H", "scale")})
+    small.append(layers[0])  # a different shape closes the group
+    for moves in (0, 4):
+        backend = sdist.HipBackend(cb, "diag", 0.01, moves, with_error=True)
+        seen = {"round": [], "many": []}
+        run_round, many = backend.run_round, backend.factorize_many
+        backend.run_round = lambda members, *a: (seen["round"].append(len(members)), run_round(members, *a))[1]
+        backend.factorize_many = lambda ls: (seen["many"].append(len(ls)), many(ls))[1]
+        shards = sdist.quantize_stream(small, backend)
+        torch.cuda.synchronize()
+        assert seen["round"] == [7] and seen["many"] == [4 - rank], (rank, seen)  # ranks 0 / 1 own 4 / 3 of the seven
+        for lay, sh in zip(small, shards):
+            lo, hi = sh["rows"]
+            res = engine.quantize_layer(lay["W"], lay["H"], cb, lay["scale"], nb_ls_moves=moves)
+            err = engine.row_errors(lay["W"], res.Q, lay["H"])
+            assert np.array_equal(sh["Q"].cpu().numpy(), res.Q[lo:hi].cpu().numpy())
+            assert np.array_equal(sh["idx"].cpu().numpy(), res.idx[lo:hi].cpu().numpy())
+            np.testing.assert_allclose(sh["row_err"].cpu().numpy(), err[lo:hi].cpu().numpy(), rtol=1e-5)
+            assert int(sh["info"].item()) == 0
     # an indefinite Hessian in a batched round: its root's status word travels in the packed factor, and EVERY rank
     # raises LinAlgError naming the layer (reference: np.linalg.cholesky, sleekit/obq.py:49-50)
     bad = [dict(lay) for lay in layers]

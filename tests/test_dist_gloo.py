@@ -153,6 +153,34 @@ class StatusBackend(FakeBatchBackend):
         self.statuses = [None if i is None else int(i.item()) for i in infos]
 
 
+class GroupingBackend(FakeBatchBackend):
+    """+ the hooks that let quantize_stream take rounds of small layers in GROUPS (HipBackend.group_limit / factorize_many)."""
+
+    def __init__(self, limit):
+        super().__init__()
+        self.limit, self.batches = limit, []
+
+    def group_limit(self, layer, rows):
+        return self.limit
+
+    def factorize_many(self, layers):
+        self.batches.append([int(lay["id"]) for lay in layers])
+        return [FakeBackend.factorize(self, lay) for lay in layers]
+
+
+def _worker_grouped(rank, size, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        layers = make_model_order_layers()
+        be = GroupingBackend(6)
+        shards = sdist.quantize_stream(layers, be)
+        q.put((rank, be.rounds, be.batches, [(s["rows"], s["Q"].numpy().copy(), int(s["info"].item())) for s in shards]))
+    finally:
+        dist.destroy_process_group()
+
+
 def make_layers_with_a_bad_one():
     layers = make_equal_layers()
     layers[3]["bad"] = 5  # its root (rank 1 of 2) reports a failing pivot: the word travels in the packed factor
@@ -306,3 +334,33 @@ def test_factor_status_reaches_every_rank_over_gloo_world2():
         p.join(timeout=30)
         assert p.exitcode == 0
     assert got[0][1] == [0, 0, 0, 5, 0, 0, 2] and got[1][1] == [0, 0, 0, 5, 0, 0, 2]
+
+
+@pytest.mark.timeout(120)
+def test_rounds_of_small_layers_in_groups_over_gloo_world2():
+    """A backend that wants up to 6 layers per loop batch: the six rounds of square layers of the model-order stream go in
+    two groups of three rounds (ONE all-gather with three slots per rank, ONE run_round over six layers, each rank's three
+    layers of a group through factorize_many), the other shapes' two-round groups likewise; shards == the unsharded result."""
+    single = sdist.quantize_stream(make_model_order_layers(), FakeBackend())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_grouped, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=90) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    square = [l for l in range(18) if l % 6 < 4]
+    for rank in range(2):
+        # groups: squares 6 + 6; (12, 6): rounds [4, 10] + [16] -> one group of 3 layers; (6, 12) likewise
+        assert got[rank][1] == [square[:6], square[6:], [4, 10, 16], [5, 11, 17]], got[rank][1]
+        # batched factorisations: three layers of each square group; of the 3-layer groups a rank owns two layers or one
+        assert [len(b) for b in got[rank][2]][:2] == [3, 3] and all(len(b) == 2 for b in got[rank][2][2:]), got[rank][2]
+    for l, layer in enumerate(make_model_order_layers()):
+        R = layer["W"].shape[0]
+        (lo0, hi0), q0, i0 = got[0][3][l]
+        (lo1, hi1), q1, i1 = got[1][3][l]
+        assert (lo0, hi1) == (0, R) and hi0 == lo1 and i0 == 0 and i1 == 0
+        assert torch.equal(torch.cat([torch.from_numpy(q0), torch.from_numpy(q1)]), single[l]["Q"])

@@ -106,6 +106,7 @@ class HipBackend:
         self.act_order, self.damp, self.moves, self.with_error = act_order, damp, nb_ls_moves, with_error
         self.local_batch = int(os.environ.get("SLK_LOCAL_BATCH", self.local_batch))            # (measurement knobs)
         self.local_batch_cols = int(os.environ.get("SLK_LOCAL_BATCH_COLS", self.local_batch_cols))
+        self.group_rows = int(os.environ.get("SLK_GROUP_ROWS", self.group_rows))
 
     def streams(self):
         """(factor streams, comm stream, loop streams), created once; (None, None, None) = everything in order."""

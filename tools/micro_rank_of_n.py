@@ -77,7 +77,7 @@ def main():
         def step():
             sdist.quantize_stream(layers, backend, join=False)
 
-        for _ in range(2):
+        for _ in range(int(os.environ.get("WARMUP", "6"))):  # (the caching allocator keeps finding new (stream, size) pairs for a few steps)
             step()
         torch.cuda.synchronize()
         calls.update(round=0, layers_in_rounds=0, rows=0)

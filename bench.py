@@ -175,8 +175,11 @@ class Leg:
         # streams and 5.1 ... 5.4 with three factor streams; N = 4: 7.9 against 8.5 ... 9.8; N = 2 keeps three factor
         # streams and rounds on them, 14.8 against 15.4)
         few_factors = world >= 4
-        launch_bound = self.widest <= 1024 and world == 1
-        self.streams = streams or ((3, 3) if launch_bound else ((2, 1) if few_factors else (3, 1)))
+        # a stream of SMALL layers only (OPT-125M: nothing wider than 3072 columns) is chains of narrow launches in batched
+        # rounds: eight streams, a hardware queue each, overlap them best (4,4: 15.3 ms per step against 19.4 with 3,1 and
+        # 17.3 with 3,3; with 4096-column layers in the stream 3,1 stays ahead: OPT-350M 63.7 against 64.7 / 73.3 ms)
+        launch_bound = self.widest <= 3072 and world == 1
+        self.streams = streams or ((4, 4) if launch_bound else ((2, 1) if few_factors else (3, 1)))
         self.backend = sdist.HipBackend(self.cb, "diag", 0.01, moves, with_error=True, overlap=self.streams)
         if few_factors:
             self.backend.rounds_on_factor_streams = False
@@ -205,6 +208,9 @@ class Leg:
         shards = sdist.quantize_stream(todo, be or self.backend, join=False)
         # flow control only: the host enqueues a step several times faster than the GPU runs it, and every step in
         # flight holds its own factors and outputs (2-3 GB); never more than four steps ahead
+        # (the step's own inputs -- the stripped Hessians of cfg3 are made per step -- stay referenced until the step is
+        # through: with join=False the side streams still read them after this returns, and memory handed back to the
+        # allocator would be reused by the next step's strip_mean on the current stream)
         fstreams, _, lstreams = (be or self.backend).streams()
         if lstreams:
             evs = []
@@ -212,9 +218,9 @@ class Leg:
                 e = torch.cuda.Event()
                 e.record(st)
                 evs.append(e)
-            self.in_flight.append(evs)
+            self.in_flight.append((evs, todo))
             if len(self.in_flight) > 4:
-                for e in self.in_flight.pop(0):
+                for e in self.in_flight.pop(0)[0]:
                     e.synchronize()
         return shards
 

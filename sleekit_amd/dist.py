@@ -534,7 +534,8 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
     `join` (default): the caller's stream waits for the loop streams before this returns, so the results can
     be used on it at once.  With join=False nothing waits: the NEXT call's factorisations then start under
     this call's loops (a throughput loop over independent batches, bench.py) -- synchronise the device, or
-    the loop streams, before reading the results.
+    the loop streams, before reading the results, and keep the INPUT tensors alive until then: the side streams still
+    read them after the call returns.
     """
     rank, size = world()
     n_layers = len(layers)

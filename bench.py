@@ -355,12 +355,13 @@ class Leg:
 
             # the whole error-update loop (SURVEY.md 8 a8 + a9: leaf chains and every blocked update = window + trailing
             # kernels; north_star prices the loop as one thing): its algorithmic float64 flops over the summed launch time
-            def loop_rate(tab):
+            def loop_rate(tab, key="total_ms"):
                 ks = [k for k in tab if k["kernel"] in LOOP_KERNELS]
-                return sum(k["total_ms"] for k in ks), sum(k["flops"] for k in ks)
+                return sum(k[key] for k in ks), sum(k["flops"] for k in ks)
 
             ms_a, fl_a = loop_rate(seq)
             ms_t, fl_t = loop_rate(table)
+            ms_c, _ = loop_rate(table, "chip_ms")
             if ms_a > 0 and ms_t > 0:
                 peak64 = PEAK["mfma_f64"][0]
                 roofline["loop"] = {
@@ -370,8 +371,13 @@ class Leg:
                     "timed": {"ms_per_layer": round(ms_t / n_steps / self.L, 4), "achieved": round(fl_t / ms_t / 1e9, 3),
                               "frac": round(fl_t / ms_t / 1e9 / (peak64 / 1e12), 4)},
                 }
+                # the same by CHIP time: a window launch of 32-row workgroups occupies R / 32 of the 256 CUs (half of them
+                # at 4096 rows) and leaves the rest to the other streams' kernels: it costs its duration times that share
+                roofline["loop"]["timed_chip_time"] = {"ms_per_layer": round(ms_c / n_steps / self.L, 4), "achieved": round(fl_t / ms_c / 1e9, 3),
+                                                       "frac": round(fl_t / ms_c / 1e9 / (peak64 / 1e12), 4)}
                 if full:
                     roofline["loop"]["timed"]["note"] = "launch durations while other layers' kernels share the CUs"
+                    roofline["loop"]["timed_chip_time"]["note"] = "launch durations x the share of the 256 CUs the launch can occupy"
             lead = max(seq, key=lambda k: k["chip_ms"])
             if lead["kernel"] != roofline["kernel"]:
                 d = describe(lead, seq)

@@ -332,6 +332,10 @@ int slk_probe_chain(double *out, int iters, int mode, slk_stream_t stream);
 /* Debug: cycle counters of workgroup 0 of the window kernel, filled when SLK_WIN_DBG has bit 3 set.
  * host_out: 80 int64 on the HOST (16 counters + 64 per-period entries of the standard-schedule kernel).  Synchronises the device.  No reference counterpart. */
 int slk_probe_window_cycles(long long *host_out, int reset);
+/* Debug: cycle counters of workgroup 1 (wave 0) of the panel kernel, filled when SLK_WIN_DBG has bit 3 set: 16 int64 on the
+ * HOST -- [0] staging, [1] diagonal-tile update, [2] pivot chains, [3] barriers and next-strip blocks, [4] tail up to the last
+ * barrier, [5] last column of L21 + stores, [15] launches counted.  Synchronises the device.  No reference counterpart. */
+int slk_probe_panel_cycles(long long *host_out, int reset);
 /* Debug: the leaf chain alone (32-column leaves, 8-level grid) on one workgroup with one or two waves per
  * SIMD.  out (DEVICE, 2 doubles): cycles wave 0 spent on `iters` leaves, checksum. */
 int slk_probe_leaf_chain(double *out, int iters, int waves_per_simd, slk_stream_t stream);

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "slk_probe_mfma_f64_acc": (c_int, [P, c_int, c_int, c_int, P]),
     "slk_probe_chain": (c_int, [P, c_int, c_int, P]),
     "slk_probe_window_cycles": (c_int, [P, c_int]),
+    "slk_probe_panel_cycles": (c_int, [P, c_int]),
     "slk_probe_leaf_chain": (c_int, [P, c_int, c_int, P]),
     "slk_profile_enable": (c_int, [c_int]),
     "slk_profile_reset": (c_int, []),

@@ -24,6 +24,9 @@ constexpr int PANEL = 64;
 constexpr int OUTER = 256;
 constexpr int LOOKAHEAD_MIN_TILES = 24;  // trailing tile rows from which an outer syrk is split (below it lasts < 25 us whole)
 
+// cycle counters of workgroup 1 of the panel kernel (wave 0; "lookahead"-free debug aid, read by slk_probe_panel_cycles)
+__device__ long long g_panel_cycles[16];
+
 constexpr int TP = 66;  // pitch of the 64 x 64 LDS tiles: MFMA operand reads walk banks 4 row + 2 k
 
 struct PanelSmem {
@@ -99,7 +102,7 @@ __device__ __forceinline__ double4_t blk_mma_a_reg(const double *a, double4_t s,
 //             the inner sum stays in registers: an accumulator tile is already the next B operand.
 // Two barriers per strip, three for the inverse.
 __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int ld, int k0, int kprev, int below, int rest_cols,
-                                                    double *__restrict__ X, int *__restrict__ info) {
+                                                    double *__restrict__ X, int *__restrict__ info, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // (blockIdx.z: the layer of a batched factorisation -- square matrices of one size, one after the other)
     A += (size_t)blockIdx.z * ld * ld;
@@ -136,46 +139,53 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
     X += (size_t)blockIdx.z * ld * ld;
     info += blockIdx.z;
     const int lane = t & 63, wave = t >> 6;
+    const bool timing = dbg && blockIdx.x == 1 && blockIdx.z == 0 && wave == 0;
+    long long tmark = timing ? (long long)__builtin_readcyclecounter() : 0;
+    auto lap = [&](int slot) {
+        if (timing) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (lane == 0) g_panel_cycles[slot] += now - tmark;
+            tmark = now;
+        }
+    };
     const bool has_prev = kprev >= 0, has_rows = blockIdx.x > 0;
 
-    // Everything this workgroup reads is fetched NOW, in one round trip: the diagonal tile, its own tile of A21 and -- when
-    // a panel of this outer block came before -- that panel's L for the diagonal tile's rows and for its own rows.
+    // Everything this workgroup reads is fetched NOW: the diagonal tile and -- when a panel of this outer block came before --
+    // that panel's L for the diagonal tile's rows FIRST (the pivots wait for them), then its own tile of A21 and that panel's
+    // L for its own rows, which land while the diagonal tile is being updated (128 KB per workgroup arrive at ~26 GB/s: 4.4 us
+    // when everything was waited for at once).
+    const int sr = t >> 2, sc8 = (t & 3) * 16;  // a thread carries 16 consecutive doubles of one row of every tile
+    double vt[16], vb[16];
     {
-        const int r = t >> 2, c8 = (t & 3) * 16;  // a thread carries 16 consecutive doubles of one row of every tile
-        const double *pd = A + (size_t)(k0 + r) * ld + k0 + c8;
-        const double *pt = A + (size_t)(k0 + PANEL * blockIdx.x + r) * ld + k0 + c8;
-        double vd[16], vt[16], vk[16], vb[16];
+        const double *pd = A + (size_t)(k0 + sr) * ld + k0 + sc8;
+        double vd[16], vk[16];
         load8d<true>(pd, *reinterpret_cast<double(*)[8]>(&vd[0]));
         load8d<true>(pd + 8, *reinterpret_cast<double(*)[8]>(&vd[8]));
-        if (has_rows) {
-            load8d<true>(pt, *reinterpret_cast<double(*)[8]>(&vt[0]));
-            load8d<true>(pt + 8, *reinterpret_cast<double(*)[8]>(&vt[8]));
-        }
         if (has_prev) {
-            const double *pk = A + (size_t)(k0 + r) * ld + kprev + c8;
+            const double *pk = A + (size_t)(k0 + sr) * ld + kprev + sc8;
             load8d<true>(pk, *reinterpret_cast<double(*)[8]>(&vk[0]));
             load8d<true>(pk + 8, *reinterpret_cast<double(*)[8]>(&vk[8]));
-            if (has_rows) {
-                const double *pl = A + (size_t)(k0 + PANEL * blockIdx.x + r) * ld + kprev + c8;
+        }
+        if (has_rows) {
+            const double *pt = A + (size_t)(k0 + PANEL * blockIdx.x + sr) * ld + k0 + sc8;
+            load8d<true>(pt, *reinterpret_cast<double(*)[8]>(&vt[0]));
+            load8d<true>(pt + 8, *reinterpret_cast<double(*)[8]>(&vt[8]));
+            if (has_prev) {
+                const double *pl = A + (size_t)(k0 + PANEL * blockIdx.x + sr) * ld + kprev + sc8;
                 load8d<true>(pl, *reinterpret_cast<double(*)[8]>(&vb[0]));
                 load8d<true>(pl + 8, *reinterpret_cast<double(*)[8]>(&vb[8]));
             }
         }
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-            const int c = c8 + e;
+            const int c = sc8 + e;
             // without an earlier panel the upper triangle is cleared (never read); with one the whole tile takes the update
-            *reinterpret_cast<double2_t *>(&sm.t[r][c]) = (double2_t){(has_prev || c <= r) ? vd[e] : 0.0, (has_prev || c + 1 <= r) ? vd[e + 1] : 0.0};
-            if (has_rows) *reinterpret_cast<double2_t *>(&sm.a21[r][c]) = (double2_t){vt[e], vt[e + 1]};
-            if (has_prev) {
-                *reinterpret_cast<double2_t *>(&sm.x[r][c]) = (double2_t){vk[e], vk[e + 1]};
-                if (has_rows) *reinterpret_cast<double2_t *>(&sm.lb[r][c]) = (double2_t){vb[e], vb[e + 1]};
-            } else {
-                *reinterpret_cast<double2_t *>(&sm.x[r][c]) = (double2_t){0.0, 0.0};
-            }
+            *reinterpret_cast<double2_t *>(&sm.t[sr][c]) = (double2_t){(has_prev || c <= sr) ? vd[e] : 0.0, (has_prev || c + 1 <= sr) ? vd[e + 1] : 0.0};
+            *reinterpret_cast<double2_t *>(&sm.x[sr][c]) = has_prev ? (double2_t){vk[e], vk[e + 1]} : (double2_t){0.0, 0.0};
         }
     }
     __syncthreads();
+    lap(0);  // staged
 
     // ---- prologue (has_prev): the previous panel's update of this panel's tile column, which used to be part of a launch
     //      of its own (k_syrk_tiles).  C -= L_rows L_diag^T, K = 64, accumulated from zero over ascending k and subtracted
@@ -200,8 +210,16 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
 #pragma unroll
             for (int cb = 0; cb <= rb; ++cb, ++i)
                 if ((i & 3) == wave) block_syrk(sm.t, sm.x, rb, cb);
-        __syncthreads();
     }
+    if (has_rows) {  // the own tile (and the previous panel's L of its rows) have landed meanwhile
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            *reinterpret_cast<double2_t *>(&sm.a21[sr][sc8 + e]) = (double2_t){vt[e], vt[e + 1]};
+            if (has_prev) *reinterpret_cast<double2_t *>(&sm.lb[sr][sc8 + e]) = (double2_t){vb[e], vb[e + 1]};
+        }
+    }
+    if (has_prev || has_rows) __syncthreads();
+    lap(1);  // diagonal tile updated, everything staged
 
     // inverse of the 16 x 16 diagonal block of strip kb: lane c < 16 owns column c of X[kb, kb] (wave 3 runs it while
     // wave 0 is in the NEXT strip's chain: the block and its reciprocal diagonal are final by then, and nothing else
@@ -230,8 +248,37 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
         blk_store_d(c, lane, blk_mma_abt(&sm.t[16 * rb][16 * kb], &sm.t[16 * cb][16 * kb], blk_load_d(c, lane), -1.0, lane));
     };
 
-    int first_bad = PANEL;  // meaningful in wave 0
+    // X[rb][cb] = -X[rb][rb] * sum_{k = cb .. rb-1} L[rb][k] X[k][cb]  (cb < rb): the inner sum stays in registers
+    auto x_block = [&](int rb, int cb) {
+        double4_t sacc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k >= cb && k < rb) sacc = blk_mma_ab(&sm.t[16 * rb][16 * k], &sm.x[16 * k][16 * cb], sacc, lane);
+        const double4_t z = {0.0, 0.0, 0.0, 0.0};
+        blk_store_d(&sm.x[16 * rb][16 * cb], lane, blk_mma_a_reg(&sm.x[16 * rb][16 * rb], sacc, z, -1.0, lane));
+    };
+    // L21[rb][cb] = sum_{k <= cb} A21[rb][k] X[cb][k]^T (X11 is lower triangular), straight to memory
+    const int r0 = k0 + PANEL * blockIdx.x;
+    auto l21_block = [&](int rb, int cb) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k <= cb) acc = blk_mma_abt(&sm.a21[16 * rb][16 * k], &sm.x[16 * cb][16 * k], acc, 1.0, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(size_t)(r0 + 16 * rb + (lane >> 4) + 4 * r) * ld + k0 + 16 * cb + (lane & 15)] = acc[r];
+    };
+    // The inverse's off-diagonal blocks and the columns of L21 do not wait for the last pivot: whatever their operands allow
+    // runs on waves 1 - 3 in the shadow of the strips' pivot chains (X[kb][kb] is known one strip after strip kb):
+    //   during strip 2: L21[:, 0]                         during strip 3: X[1][0], L21[:, 1]
+    //   after the chain: X[2][0], X[2][1] beside the last diagonal block's inverse | X[3][0..2], L21[:, 2] | L21[:, 3]
+    // -- 2.8 us after the last pivot instead of 6.3 (three levels of the inverse, then the whole of L21).
+
+    int first_bad = PANEL;  // meaningful in wave 0
+#ifdef SLK_PANEL_ROLLED
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
     for (int kb = 0; kb < 4; ++kb) {
         const int c0 = 16 * kb;
         if (wave == 0) {
@@ -258,6 +305,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
 #pragma unroll
                 for (int c = 0; c < 16; ++c) sm.t[row][c0 + c] = (c0 + c <= row) ? a[c] : 0.0;
             }
+            lap(2);  // pivot chains
         } else if (kb == 0) {
             if (has_prev && has_rows) {  // the own tile's update (see the prologue), 16 blocks over waves 1 - 3
 #pragma unroll
@@ -275,6 +323,19 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
 #pragma unroll
                 for (int cb = kb + 1; cb <= rb; ++cb)
                     if (block_owner(rb, cb) == wave) block_update(rb, cb, kb - 1);
+            if (kb == 2 && has_rows) {  // X[0][0] is in (strip 1's side work)
+                l21_block(wave - 1, 0);
+                l21_block(wave + 1, 0);
+            }
+            if (kb == 3 && wave == 1) {  // X[1][1] is in (strip 2's side work)
+                x_block(1, 0);
+                // (this wave reads the block back at once: LDS operations of one wave complete in order)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (has_rows) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) l21_block(rb, 1);
+                }
+            }
         }
         __syncthreads();
         if (kb == 0 && has_prev) {  // the previous panel's L has served: x is the inverse's from here on (zero above the diagonal)
@@ -287,27 +348,25 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
                 if (block_owner(rb, kb + 1) == wave) block_update(rb, kb + 1, kb);
             __syncthreads();
         }
+        lap(3);  // barriers + next-strip blocks
     }
+    // ---- after the last pivot
     if (wave == 3) diag_inverse(3);
+    else if (wave == 0) x_block(2, 0);  // X[2][2] came with strip 3's side work, X[1][0] too
+    else if (wave == 1) x_block(2, 1);
     __syncthreads();
     if (first_bad != PANEL && blockIdx.x == 0 && t == 0 && info[0] == 0) info[0] = k0 + first_bad + 1;
-
-    // ---- off-diagonal blocks of X = inv(L11), by distance d from the diagonal
-#pragma unroll
-    for (int d = 1; d < 4; ++d) {
-#pragma unroll
-        for (int rb = d; rb < 4; ++rb) {
-            if (((rb - d) & 3) == wave) {
-                const int cb = rb - d;
-                double4_t s = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int k = cb; k < rb; ++k) s = blk_mma_ab(&sm.t[16 * rb][16 * k], &sm.x[16 * k][16 * cb], s, lane);
-                const double4_t z = {0.0, 0.0, 0.0, 0.0};
-                blk_store_d(&sm.x[16 * rb][16 * cb], lane, blk_mma_a_reg(&sm.x[16 * rb][16 * rb], s, z, -1.0, lane));
-            }
+    if (wave < 3) x_block(3, wave);
+    if (has_rows) {  // L21[:, 2] wants X[2][0 .. 2]: wave 3 two row blocks, waves 1 and 2 one each behind their X block
+        if (wave == 3) {
+            l21_block(0, 2);
+            l21_block(1, 2);
+        } else if (wave > 0) {
+            l21_block(wave + 1, 2);
         }
-        __syncthreads();
     }
+    __syncthreads();
+    lap(4);  // tail: last diagonal inverse, X rows 2 and 3, L21[:, 2]
 
     if (blockIdx.x == 0) {
         for (int e = t; e < PANEL * PANEL; e += 256) {
@@ -316,19 +375,9 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
         }
         return;
     }
-    // ---- L21 = A21 * X11^T for this block's 64 rows, straight from the two LDS images: wave w owns the row block w,
-    //      and X11 is lower triangular, so column block cb takes the k blocks 0 .. cb only (10 block products per wave
-    //      instead of 16).  (The last barrier above made X complete; A21 was staged after the first strip.)
-    const int r0 = k0 + PANEL * blockIdx.x;
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k <= cb; ++k) acc = blk_mma_abt(&sm.a21[16 * wave][16 * k], &sm.x[16 * cb][16 * k], acc, 1.0, lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            A[(size_t)(r0 + 16 * wave + (lane >> 4) + 4 * r) * ld + k0 + 16 * cb + (lane & 15)] = acc[r];
-    }
+    l21_block(wave, 3);  // the last block column wants the whole last block row of X
+    lap(5);
+    if (timing && lane == 0) g_panel_cycles[15] += 1;
 }
 
 // C[bi][bj] -= L[bi][ka:kb] * L[bj][ka:kb]^T for tiles bi in [ti0, ti1), bj in [tj0, tj1), bj <= bi.
@@ -488,7 +537,8 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
             SLK_RUN_W("chol_panel",
                       Bd * (2.0 / 3.0 * 64 * 64 * 64 + (double)(below - 1) * 64 * 64 * 64 + prologue + (double)rest * 2.0 * 64 * 64 * PANEL),
                       Bd * (16.0 * below * 64 * 64 + (double)rest * 16.0 * 64 * 64), (below + rest) * batch, s,
-                      k_chol_panel<<<dim3(below + rest, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, k0, kprev, below, rest_cols, X, info));
+                      k_chol_panel<<<dim3(below + rest, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, k0, kprev, below, rest_cols, X, info,
+                                                                                            opt(OPT_WIN_DBG) & 8));
         }
         const int t0 = K1 / TILE;
         if (nt > t0) {
@@ -564,6 +614,17 @@ extern "C" int slk_chol_inverse_upper_batch(double *A, int batch, int n, double 
     SLK_REQUIRE(A && U && info && n > 0, "bad arguments");
     SLK_REQUIRE(batch >= 1 && batch <= 64, "batch must be 1..64");
     return chol_inverse_impl(A, batch, n, U, info, workspace, ws_bytes, stream, false);
+}
+
+extern "C" int slk_probe_panel_cycles(long long *host_out, int reset) {
+    SLK_REQUIRE(host_out, "null pointer");
+    SLK_HIP(hipDeviceSynchronize());
+    SLK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_panel_cycles), sizeof(long long) * 16));
+    if (reset) {
+        long long zero[16] = {0};
+        SLK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_panel_cycles), zero, sizeof(zero)));
+    }
+    return SLK_OK;
 }
 
 extern "C" size_t slk_factor_workspace_bytes_batch(int batch, int n) {

@@ -20,7 +20,7 @@ rows of every layer across the ranks (sleekit_amd/dist.py); the factors are made
 xGMI once, in one RCCL all-gather per round of N same-shaped layers.  Total work is the same at every N ("strong").
 
 The ONE JSON line carries the headline run and, unless --no-configs / --config is given, every other BASELINE config
-as a short leg of its own under "configs" (cfg2, cfg3, cfg4: 3 steps; cfg5: 2 steps of 16 of its 32 layers), each with its
+as a short leg of its own under "configs" (cfg2: 8 steps, cfg3, cfg4: 5; cfg5: 2 steps of 16 of its 32 layers), each with its
 own roofline and CPU baseline, so that one driver run backs every number of DESIGN.md's table.  Fields besides the contract's:
   roofline      for the kernel with the largest share of the chip's time IN THE TIMED CONFIGURATION (HIP events
                  around every launch, on the launch stream: slk_profile_* in the C ABI; a launch of fewer than 256
@@ -85,7 +85,7 @@ WORKLOADS = {
     "cfg5": dict(name="Llama-FFN 4096x11008 x 32", block=[(4096, 11008)], blocks=32, levels=4, moves=0, strip=False),
 }
 # the short legs of the default run: (steps, warm-up, blocks of the model; 0 = all)
-CONFIG_LEGS = {"cfg2": (3, 1, 0), "cfg3": (3, 1, 0), "cfg4": (3, 1, 0), "cfg5": (2, 1, 16)}
+CONFIG_LEGS = {"cfg2": (8, 2, 0), "cfg3": (5, 2, 0), "cfg4": (5, 2, 0), "cfg5": (2, 1, 16)}
 
 
 def parse():
@@ -165,6 +165,9 @@ class Leg:
             if key not in self.made:
                 lay = synth.make_layer_device(R, n, 1000 + i, env.device)
                 self.made[key] = {k: lay[k] for k in ("W", "H", "scale", "mean")}
+                # checked ONCE, here: the synthetic Hessians are bit-wise symmetric (sums of exact products in float64), and
+                # the layer says so -- no symmetry check per step, and a searched layer's error is the one the search carries
+                self.made[key]["symmetric"] = bool(torch.equal(lay["H"], lay["H"].T))
             self.layers.append(self.made[key])
         torch.cuda.synchronize()
         self.t_setup = time.time() - t0
@@ -585,7 +588,7 @@ def main():
                 # mean magnitude above the diagonal)
                 gemm_symmetric = gemm_symmetric and bool(torch.equal(Ha, Ha.T))
                 Ha = Ha + torch.triu(torch.randn_like(Ha), 1) * (1e-6 * float(Ha.abs().mean()))
-                alt[id(lay)] = dict(lay, H=Ha)
+                alt[id(lay)] = dict(lay, H=Ha, symmetric=False)
         alt_layers = [alt[id(lay)] for lay in head.layers]
         symmetric = all(bool(torch.equal(a["H"], a["H"].T)) for a in alt.values())
         el, _ = head.timed(args.steps, 1, alt_layers)

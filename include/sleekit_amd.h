@@ -67,7 +67,8 @@ typedef void *slk_stream_t;
  * (slk_hessian_prepare_batch, slk_chol_inverse_upper_batch, slk_factor_workspace_bytes_batch); 5 adds codebook training
  * (slk_codebook_stats, slk_sort_f32, slk_unique_f32), slk_local_search_batch and slk_factor_unpack_upper_batch; 6 adds
  * slk_chol_inverse_upper_lookahead and slk_release_helpers (the look-ahead is an argument of the call, not a process-wide switch)
- * and turns the loop's `unscale` argument into `flags` (SLK_LOOP_UNSCALE = 1 as before, SLK_LOOP_LATENCY = 2).                                                          */
+ * and turns the loop's `unscale` argument into `flags` (SLK_LOOP_UNSCALE = 1 as before, SLK_LOOP_LATENCY = 2); slk_local_search(_batch)
+ * gain `row_err` (the rows' errors after the moves), slk_probe_panel_cycles is new.                                                          */
 int slk_abi_version(void);
 const char *slk_last_error(void);
 /* Run-time switches between code paths that give the same results (the tests hold them to that) or that shape a
@@ -279,18 +280,23 @@ int slk_symmetry_flag(const float *H, int n, int *flag, slk_stream_t stream);
  *     R x 2 x n float32, per row the n up-gains then the n down-gains.  gains_mode 0: none (gains may be NULL);
  *     1: the initial gains are built from (W - Q) H as usual, and the gains after the moves are stored (moves == 0
  *     gives the constructor's state, obq.py:259-262); 2: the gains are LOADED, the moves made, the gains stored --
- *     k calls with moves = 1 are then one call with moves = k, bit for bit, like k calls of do_move().       */
+ *     k calls with moves = 1 are then one call with moves = k, bit for bit, like k calls of do_move().
+ *     row_err (may be NULL; gains_mode 0 or 1): R float32, the rows' errors (W - Q) H (W - Q)^T AFTER the moves, in the domain of
+ *     W and Q: the error before them comes out of the product that makes the initial gains, and every move takes its gain off
+ *     it -- how the reference's LocalSearchQuantizer carries `err` (obq.py:254, 290) -- so the layer error of a searched layer
+ *     needs no product of its own (a row shard of BLOOM-560M spent as long on that product as on the search).                */
 int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
                      double hi, const float *table, int moves, uint8_t *idx, int *trace, float *gains,
-                     int gains_mode, void *workspace, size_t ws_bytes, slk_stream_t stream);
+                     int gains_mode, float *row_err, void *workspace, size_t ws_bytes, slk_stream_t stream);
 /* The same search over `batch` layers of one shape stacked by rows (rows [b R, (b + 1) R) of W, Q, idx against H[b], a
  * HOST array of `batch` device pointers; R = rows_per_layer, a multiple of 128 when batch > 1): the results of `batch`
  * separate calls bit for bit, in ONE product and ONE launch of moves -- the row shards of a round on several ranks (a few
  * hundred rows per layer) are bound by the host's launch rate otherwise.  symmetric: as in slk_row_errors_batch (may be NULL).
+ * row_err (may be NULL): batch * rows_per_layer float32, the rows' errors after the moves (see slk_local_search).
  * Workspace: slk_workspace_bytes_batch(batch, rows_per_layer, n).                                                     */
 int slk_local_search_batch(const float *W, float *Q, const float *const *H, int batch, int rows_per_layer, int n,
                            int levels, double lo, double hi, const float *table, int moves, uint8_t *idx,
-                           const int *symmetric, void *workspace, size_t ws_bytes, slk_stream_t stream);
+                           const int *symmetric, float *row_err, void *workspace, size_t ws_bytes, slk_stream_t stream);
 
 /* Scale selection: the callers' pre-step -------------------------- */
 /* compute_non_saturating_scaling (sleekit/scaling.py:44-55): scale[r] = max(max_r / hi_code,

@@ -73,8 +73,8 @@ PROTOTYPES = {
     "slk_row_errors": (c_int, [P, P, P, c_int, c_int, P, P, P, c_size_t, P]),
     "slk_row_errors_batch": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, c_size_t, P]),
     "slk_symmetry_flag": (c_int, [P, c_int, P, P]),
-    "slk_local_search": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P, P, c_int, P, c_size_t, P]),
-    "slk_local_search_batch": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P, P, c_size_t, P]),
+    "slk_local_search": (c_int, [P, P, P, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P, P, c_int, P, P, c_size_t, P]),
+    "slk_local_search_batch": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_double, c_double, P, c_int, P, P, P, P, c_size_t, P]),
     "slk_scale_minmax": (c_int, [P, c_int, c_int, c_double, c_double, P, P]),
     "slk_scale_norm": (c_int, [P, c_int, c_int, P, P]),
     "slk_scale_search": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_double, c_double, P, P, P]),

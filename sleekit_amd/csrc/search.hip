@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
                                                       PtrTable hs, int rpl, const float *__restrict__ G,
                                                       const float *__restrict__ hdiag, int R, int n, Grid g,
                                                       int moves, uint8_t *__restrict__ idx, int *__restrict__ trace,
-                                                      float *__restrict__ gains, int gains_mode) {
+                                                      float *__restrict__ gains, int gains_mode, float *__restrict__ row_err) {
     // (a stack of layers by rows: rows [b rpl, (b + 1) rpl) search against Hessian b)
     const float *__restrict__ H = hs.p[blockIdx.x / rpl];
     hdiag += (size_t)(blockIdx.x / rpl) * n;
@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         }
     }
 
+    // the row's error, carried like the reference's own (obq.py:290, `self.err[r] -= gain` per move): in: the error of the
+    // rows as they come (from the product that made G), out: the error after the moves -- no second product for it
+    float e_run = row_err ? row_err[row] : 0.0f;
     int mv = 0;
     for (; mv < moves; ++mv) {
         // ---- best up / best down of the row
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         // (oracle/obq_ref.py: move_record counts the reference's non-moves as "stay").
         if (q_new == q_old) break;
         if (trace && t == 0) trace[(size_t)row * moves + mv] = 2 * c + (go_up ? 1 : 0);
+        e_run = e_run - (go_up ? bu.v : bd.v);
 
         // ---- stream row c of H: the products of the interaction sum with the OLD Q (obq.py:328), and part 2
         //      off the moved column
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
     }
     if (trace && t == 0)
         for (; mv < moves; ++mv) trace[(size_t)row * moves + mv] = -1;
+    if (row_err && t == 0) row_err[row] = e_run;
 
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
                                                            PtrTable hs, int rpl, const float *__restrict__ G,
                                                            const float *__restrict__ hdiag, int R, int n, Grid g, int moves,
                                                            uint8_t *__restrict__ idx, int *__restrict__ trace,
-                                                           float *__restrict__ gains, int gains_mode) {
+                                                           float *__restrict__ gains, int gains_mode, float *__restrict__ row_err) {
     constexpr int EPT = M8 * S;
     __shared__ Best red_up[4], red_dn[4];
     __shared__ float red_s[2][4];
@@ -251,6 +256,9 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
         }
     }
 
+    // the row's error, carried like the reference's own (obq.py:290, `self.err[r] -= gain` per move): in: the error of the
+    // rows as they come (from the product that made G), out: the error after the moves -- no second product for it
+    float e_run = row_err ? row_err[row] : 0.0f;
     int mv = 0;
     for (; mv < moves; ++mv) {
         Best bu = {NEG, 0x7fffffff, 0.0f}, bd = {NEG, 0x7fffffff, 0.0f};
@@ -279,6 +287,7 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
         const float q_new = go_up ? cand_up(q_old, g) : cand_down(q_old, g);
         if (q_new == q_old) break;  // a "move" onto the same value: see k_local_search
         if (trace && tr == 0) trace[(size_t)row * moves + mv] = 2 * c + (go_up ? 1 : 0);
+        e_run = e_run - (go_up ? bu.v : bd.v);
 
         const float *hrow = H + (size_t)c * n;
         const float two_dq = 2.0f * (q_old - q_new);
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
     }
     if (trace && tr == 0)
         for (; mv < moves; ++mv) trace[(size_t)row * moves + mv] = -1;
+    if (row_err && tr == 0) row_err[row] = e_run;
 
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -359,11 +369,13 @@ using namespace slk;
 // then bounds the rank: BLOOM-560M on 8 ranks spent 18 of its 34 ms per step enqueueing).
 static int local_search_impl(const float *W, float *Q, const float *const *Hs, int batch, int rpl, int n, int levels, double lo,
                              double hi, const float *table, int moves, uint8_t *idx, int *trace, float *gains,
-                             int gains_mode, const int *sym_known, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+                             int gains_mode, const int *sym_known, float *row_err_out, void *workspace, size_t ws_bytes,
+                             slk_stream_t stream) {
     const int R = batch * rpl;
+    SLK_REQUIRE(row_err_out == nullptr || gains_mode != 2, "the carried error needs the initial product (gains_mode 0 or 1)");
     Arena ws(workspace, ws_bytes);
     float *G = ws.take<float>((size_t)R * n);
-    float *row_err = ws.take<float>((size_t)R);
+    float *row_err = row_err_out ? row_err_out : ws.take<float>((size_t)R);
     float *hdiag = ws.take<float>((size_t)n * batch);
     if (!G || !row_err || !hdiag) {
         set_error("workspace too small");
@@ -386,7 +398,7 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
     do {                                                                                                            \
         SLK_LDS_OPT_IN(k_local_search<E>, lds);                                                                     \
         SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                       \
-                k_local_search<E><<<R, 256, lds, s>>>(W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode)); \
+                k_local_search<E><<<R, 256, lds, s>>>(W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode, row_err_out)); \
     } while (0)
     // regular row lengths (8 or 16 leaves of m <= 128 elements, m % 8 == 0): one wave per row, no LDS, no barrier
     {
@@ -406,7 +418,7 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
     if (regular && m8 == M8 && leaves == LEAVES) {                                                                      \
         SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                           \
                 k_local_search_wave<M8, S, WAVES><<<WAVES == 1 ? (R + 3) / 4 : R, 256, 0, s>>>(                         \
-                    W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode));                           \
+                    W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode, row_err_out));              \
         return SLK_OK;                                                                                                  \
     }
         if (R >= 2048 || wave_opt < 0) {  // a wave per row: 8 or 16 leaves
@@ -434,19 +446,19 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
 
 extern "C" int slk_local_search(const float *W, float *Q, const float *H, int R, int n, int levels, double lo,
                                 double hi, const float *table, int moves, uint8_t *idx, int *trace, float *gains,
-                                int gains_mode, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+                                int gains_mode, float *row_err, void *workspace, size_t ws_bytes, slk_stream_t stream) {
     SLK_REQUIRE(W && Q && H && R > 0 && n > 0 && moves >= 0, "bad arguments");
     SLK_REQUIRE(levels >= 2 && (table || lo < hi), "codebook needs levels >= 2 and lo < hi");
     SLK_REQUIRE(idx == nullptr || levels <= 256, "uint8 indices need levels <= 256");
     SLK_REQUIRE(n <= 256 * 64, "local search supports n <= 16384");
     SLK_REQUIRE(gains_mode >= 0 && gains_mode <= 2 && (gains_mode == 0 || gains), "gains_mode 1 / 2 needs the gains buffer");
-    return local_search_impl(W, Q, &H, 1, R, n, levels, lo, hi, table, moves, idx, trace, gains, gains_mode, nullptr, workspace, ws_bytes,
-                             stream);
+    return local_search_impl(W, Q, &H, 1, R, n, levels, lo, hi, table, moves, idx, trace, gains, gains_mode, nullptr, row_err, workspace,
+                             ws_bytes, stream);
 }
 
 extern "C" int slk_local_search_batch(const float *W, float *Q, const float *const *H, int batch, int rows_per_layer, int n,
                                       int levels, double lo, double hi, const float *table, int moves, uint8_t *idx,
-                                      const int *symmetric, void *workspace, size_t ws_bytes, slk_stream_t stream) {
+                                      const int *symmetric, float *row_err, void *workspace, size_t ws_bytes, slk_stream_t stream) {
     SLK_REQUIRE(W && Q && H && rows_per_layer > 0 && n > 0 && moves >= 0, "bad arguments");
     SLK_REQUIRE(batch >= 1 && batch <= 64, "batch must be 1..64");
     SLK_REQUIRE(batch == 1 || rows_per_layer % 128 == 0, "a batch needs rows_per_layer to be a multiple of 128");
@@ -455,7 +467,7 @@ extern "C" int slk_local_search_batch(const float *W, float *Q, const float *con
     SLK_REQUIRE(n <= 256 * 64, "local search supports n <= 16384");
     SLK_REQUIRE((long long)batch * rows_per_layer <= 0x7fffffffLL, "too many rows");
     for (int b = 0; b < batch; ++b) SLK_REQUIRE(H[b], "null Hessian in the batch");
-    return local_search_impl(W, Q, H, batch, rows_per_layer, n, levels, lo, hi, table, moves, idx, nullptr, nullptr, 0, symmetric, workspace,
-                             ws_bytes, stream);
+    return local_search_impl(W, Q, H, batch, rows_per_layer, n, levels, lo, hi, table, moves, idx, nullptr, nullptr, 0, symmetric, row_err,
+                             workspace, ws_bytes, stream);
 }
 

@@ -168,8 +168,19 @@ class HipBackend:
             miss = eng.column_miss(Ws, cb, mode == 3)
         factor = eng.factorize(H, n, self.damp, mode, miss)
         if self.with_error:  # the layer error wants to know whether H is symmetric: decided here, once per layer
-            factor = factor + (eng.symmetry_flag(H),)
+            factor = factor + (self._symmetry(layer),)
         return factor
+
+    def _symmetry(self, layer):
+        """int32[1] on the device: 1 iff H is bit-wise symmetric.  A layer dict may VOUCH for it (`symmetric=True`: the caller
+        has checked, e.g. once when the statistics were loaded): no check per call then, and a searched layer's error can be
+        the one the search carries (see _run_stacked)."""
+        if layer.get("symmetric") is True:
+            dev_ = layer["H"].device
+            if getattr(self, "_yes", None) is None or self._yes.device != dev_:
+                self._yes = torch.ones(1, dtype=torch.int32, device=dev_)
+            return self._yes
+        return self.engine.symmetry_flag(layer["H"])
 
     def factorize_many(self, layers):
         """The factors of several layers of ONE width in launches that cover them all (engine.factorize_batch: bit-equal to
@@ -184,7 +195,7 @@ class HipBackend:
         for b, lay in enumerate(layers):
             fac = (order[b], U[b], info[b:b + 1])
             if self.with_error:
-                fac = fac + (eng.symmetry_flag(lay["H"]),)
+                fac = fac + (self._symmetry(lay),)
             out.append(fac)
         return out
 
@@ -228,9 +239,12 @@ class HipBackend:
         sc = layer["scale"][lo:hi].contiguous() if layer.get("scale") is not None else None
         # (lookahead = "alone on the GPU": with overlapping streams the loop takes the window kernel's least-chip-time form)
         res = eng.quantize_layer(W, layer["H"], self.quantizer, sc, self.act_order, self.damp, self.moves, factor=factor[:3],
-                                 lookahead=not self.overlap)
+                                 lookahead=not self.overlap,
+                                 want_ls_error=self.with_error and self.moves > 0 and layer.get("symmetric") is True)
         err = None
-        if self.with_error and len(factor) > 3:  # the verdict on H's symmetry came with the factor
+        if res.ls_error is not None:  # carried through the search (scaled domain: times scale^2)
+            err = res.ls_error if sc is None else (res.ls_error * sc) * sc
+        elif self.with_error and len(factor) > 3:  # the verdict on H's symmetry came with the factor
             err = eng.row_errors_batch(W[None], res.Q[None], [layer["H"]], factor[3])[0]
         elif self.with_error:
             err = eng.row_errors(W, res.Q, layer["H"])
@@ -345,14 +359,23 @@ class HipBackend:
             # rows never interact, they are cut off below.)
             Ws = eng.rows_divide(W.view(B * Rp, n), sc.reshape(-1)).view(B, Rp, n) if sc is not None else W
             Q, idx = eng.run_loop_batch(Ws, None, order, U, cb, 32, 8, want_idx=want_idx)
-            eng.local_search_batch(Ws, Q, [lay["H"] for lay in round_layers], cb, self.moves, idx if want_idx else None, known)
+            # Hessians the caller vouches to be symmetric (layer["symmetric"] is True): the search carries every row's error with
+            # it (obq.py:254, 290 -- the gain of a move IS the change of the error when H is symmetric), so the layer error
+            # needs no product of its own; it comes out in the scaled domain, (W - Qw) = scale (Ws - Q): times scale^2.
+            # Per row it is as exact as the reference's own `ls.err` (float32 gains: a few 1e-5 relative on a rare row), the
+            # layer's mean agrees with the recomputed product to ~1e-8 (BLOOM-560M, all 96 layers).
+            carried = self.with_error and all(lay.get("symmetric") is True for lay in round_layers)
+            err = torch.empty((B, Rp), dtype=torch.float32, device=device) if carried else None
+            eng.local_search_batch(Ws, Q, [lay["H"] for lay in round_layers], cb, self.moves, idx if want_idx else None, known, err)
             if sc is not None:
                 Q = eng.rows_divide(Q.view(B * Rp, n), sc.reshape(-1), invert=True).view(B, Rp, n)
+                if err is not None:
+                    err = (err * sc) * sc
+            if self.with_error and err is None:
+                err = eng.row_errors_batch(W, Q, [lay["H"] for lay in round_layers], known)
         else:
             Q, idx = eng.run_loop_batch(W, sc, order, U, cb, 32, 8, want_idx=want_idx, unscale=sc is not None)
-        err = None
-        if self.with_error:
-            err = eng.row_errors_batch(W, Q, [lay["H"] for lay in round_layers], known)
+            err = eng.row_errors_batch(W, Q, [lay["H"] for lay in round_layers], known) if self.with_error else None
         return [dict(Q=Q[b, :rows], idx=idx[b, :rows] if want_idx else None, row_err=None if err is None else err[b, :rows], rows=(lo, hi),
                      info=info[b:b + 1]) for b in range(B)]
 

@@ -73,10 +73,10 @@ def require_uniform(quantizer):
 class LayerResult:
     """Device tensors produced for one layer."""
 
-    __slots__ = ("Q", "idx", "order", "U", "info", "E", "ls_trace")
+    __slots__ = ("Q", "idx", "order", "U", "info", "E", "ls_trace", "ls_error")
 
     def __init__(self):
-        self.Q = self.idx = self.order = self.U = self.info = self.E = self.ls_trace = None
+        self.Q = self.idx = self.order = self.U = self.info = self.E = self.ls_trace = self.ls_error = None
 
 
 def factorize(H, n, damp, mode, miss=None, keep=None, lookahead=False):
@@ -204,9 +204,10 @@ def symmetry_flag(H):
     return flag
 
 
-def local_search(W, Q, H, cb_abi, moves, idx=None, want_trace=False, gains=None, gains_mode=0):
+def local_search(W, Q, H, cb_abi, moves, idx=None, want_trace=False, gains=None, gains_mode=0, row_err=None):
     """In place on Q (and idx).  want_trace: returns the (R, moves) int32 record of the moves taken
-    (2 * column + up, -1 = none); gains / gains_mode: the carried state of a stateful search (slk_local_search)."""
+    (2 * column + up, -1 = none); gains / gains_mode: the carried state of a stateful search (slk_local_search);
+    row_err (R,) float32: receives the rows' errors (W - Q) H (W - Q)^T after the moves."""
     R, n = W.shape
     levels, lo, hi, table = cb_abi
     ws, ws_bytes = dev.workspace(R, n)
@@ -215,15 +216,16 @@ def local_search(W, Q, H, cb_abi, moves, idx=None, want_trace=False, gains=None,
     _lib.check(
         _lib.lib.slk_local_search(
             dev.ptr(W), dev.ptr(Q), dev.ptr(H), R, n, levels, lo, hi, dev.ptr(table), int(moves), dev.ptr(idx), dev.ptr(trace),
-            dev.ptr(gains), int(gains_mode), dev.ptr(ws), ws_bytes, dev.stream_handle(),
+            dev.ptr(gains), int(gains_mode), dev.ptr(row_err), dev.ptr(ws), ws_bytes, dev.stream_handle(),
         )
     )
     return trace
 
 
-def local_search_batch(W, Q, Hs, cb_abi, moves, idx=None, symmetric=None):
+def local_search_batch(W, Q, Hs, cb_abi, moves, idx=None, symmetric=None, row_err=None):
     """local_search over a batch of layers stacked by rows: W, Q (B, R, n) (idx (B, R, n) uint8 or None), Hs a list of B
-    Hessians; in place on Q and idx, the results of B separate searches."""
+    Hessians; in place on Q and idx, the results of B separate searches.  row_err (B, R) float32: receives the rows' errors
+    after the moves, in the domain of W and Q (carried through the search: no product of its own)."""
     import ctypes
 
     B, R, n = W.shape
@@ -233,7 +235,7 @@ def local_search_batch(W, Q, Hs, cb_abi, moves, idx=None, symmetric=None):
     ptrs = (ctypes.c_void_p * B)(*[dev.ptr(H) for H in Hs])
     _lib.check(
         _lib.lib.slk_local_search_batch(dev.ptr(W), dev.ptr(Q), ptrs, B, R, n, levels, lo, hi, dev.ptr(table), int(moves), dev.ptr(idx),
-                                        dev.ptr(symmetric), dev.ptr(ws), ws_bytes, dev.stream_handle())
+                                        dev.ptr(symmetric), dev.ptr(row_err), dev.ptr(ws), ws_bytes, dev.stream_handle())
     )
 
 
@@ -273,7 +275,7 @@ def row_errors(W, Q, H, want_G=False):
 
 def quantize_layer(
     W, H, quantizer, scale=None, act_order="diag", damp=0.01, nb_ls_moves=0, min_block_size=32, num_blocks=8,
-    factor=None, unscale=True, want_idx=True, want_ls_trace=False, lookahead=True,
+    factor=None, unscale=True, want_idx=True, want_ls_trace=False, lookahead=True, want_ls_error=False,
 ):
     """One layer through the whole path, on device tensors.
 
@@ -313,7 +315,9 @@ def quantize_layer(
     fused = scale is not None and unscale and nb_ls_moves == 0 and loop_scale is not None
     res.Q, res.idx, _ = run_loop(Ws, loop_scale, res.order, res.U, cb_abi, min_block_size, num_blocks, want_idx, unscale=fused, latency=lookahead)
     if nb_ls_moves > 0:
-        res.ls_trace = local_search(Ws, res.Q, H, cb_abi, nb_ls_moves, res.idx, want_trace=want_ls_trace)
+        if want_ls_error:  # the rows' errors after the moves, in the scaled domain (res.ls_error)
+            res.ls_error = torch.empty(R, dtype=torch.float32, device=W.device)
+        res.ls_trace = local_search(Ws, res.Q, H, cb_abi, nb_ls_moves, res.idx, want_trace=want_ls_trace, row_err=res.ls_error)
     if scale is not None and unscale and not fused:
         res.Q = rows_divide(res.Q, scale, invert=True)
     return res

@@ -76,7 +76,7 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert _lib.lib.slk_hessian_prepare_batch(one, 65, 64, 0.01, _lib.ORDER_DIAG, 8, 8, None, 0, None) == _lib.E_ARG
     assert _lib.lib.slk_chol_inverse_upper_batch(8, 0, 64, 8, 8, None, 0, None) == _lib.E_ARG
     assert _lib.lib.slk_factor_workspace_bytes_batch(8, 768) >= 8 * 2 * 768 * 768 * 8
-    assert _lib.lib.slk_local_search(8, 8, 8, 4, 4, 8, -1.0, 1.0, None, 1, None, None, None, 2, None, 0, None) == _lib.E_ARG
+    assert _lib.lib.slk_local_search(8, 8, 8, 4, 4, 8, -1.0, 1.0, None, 1, None, None, None, 2, None, None, 0, None) == _lib.E_ARG
     assert b"gains" in _lib.lib.slk_last_error()
     with pytest.raises(RuntimeError):
         _lib.check(_lib.E_ARG)

@@ -686,6 +686,50 @@ def test_local_search_wave_kernel_is_the_workgroup_kernel(amd, n):
         assert len(bad) <= 1  # (a near-tie of the initial product may fall the other way: proven elsewhere, ls_evidence.py)
 
 
+@pytest.mark.parametrize("n", [172, 768, 1024, 4096])
+def test_local_search_carries_the_row_errors(amd, n):
+    """slk_local_search's `row_err`: every row's error (W - Q) H (W - Q)^T after the moves, carried through the search the way
+    the reference's LocalSearchQuantizer carries `err` (obq.py:254, 290: the error before, minus the gain of every move) --
+    against the product recomputed from the final Q (what quantization_error does, obq.py:89-103), both kernel families."""
+    R = 70
+    L = synth.make_layer_device(R, n, 4300 + n, torch.device("cuda"))
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    abi = cb._abi()
+    Ws = amd.engine.rows_divide(L["W"], L["scale"])
+    for general in (-1, 1):
+        with amd.lib.option("no_wave_search", general):
+            Q = cb.quantize_value(Ws)
+            carried = torch.empty(R, dtype=torch.float32, device="cuda")
+            trace = amd.engine.local_search(Ws, Q, L["H"], abi, 15, want_trace=True, row_err=carried)
+            assert int((trace >= 0).sum()) > R
+            again = amd.engine.row_errors(Ws, Q, L["H"])
+            # per row: float32 gains, as exact as the reference's own `ls.err`; the layer's mean: far inside 1e-5
+            np.testing.assert_allclose(carried.cpu().numpy(), again.cpu().numpy(), rtol=2e-4)
+            assert abs(float(carried.double().mean()) - float(again.double().mean())) <= 1e-6 * float(again.double().mean())
+    # end to end through the row-shard backend: a layer that VOUCHES for its Hessian's symmetry gets the carried error,
+    # de-scaled; one that does not gets the recomputed product (an asymmetric H would make the carried one wrong)
+    from sleekit_amd import dist as sdist
+
+    assert torch.equal(L["H"], L["H"].T)
+    be = sdist.HipBackend(cb, "diag", 0.01, 10, with_error=True, overlap=False)
+    calls = []
+    row_errors_batch = amd.engine.row_errors_batch
+    try:
+        amd.engine.row_errors_batch = lambda *a, **k: (calls.append(1), row_errors_batch(*a, **k))[1]
+        for vouched in (True, False):
+            lay = {k: L[k] for k in ("W", "H", "scale")}
+            if vouched:
+                lay["symmetric"] = True
+            del calls[:]
+            shard = be.run_rows(lay, 0, R, be.factorize(lay))
+            assert len(calls) == (0 if vouched else 1)
+            want = amd.engine.row_errors(L["W"], shard["Q"], L["H"])
+            np.testing.assert_allclose(shard["row_err"].cpu().numpy(), want.cpu().numpy(), rtol=2e-4 if vouched else 1e-5)
+            assert abs(float(shard["row_err"].double().mean()) - float(want.double().mean())) <= 1e-6 * float(want.double().mean())
+    finally:
+        amd.engine.row_errors_batch = row_errors_batch
+
+
 def test_hessian_accumulate(amd, pieces):
     X = pieces["stats/X"]
     lin = torch.nn.Linear(48, 10).cuda()

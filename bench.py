@@ -85,7 +85,7 @@ WORKLOADS = {
     "cfg5": dict(name="Llama-FFN 4096x11008 x 32", block=[(4096, 11008)], blocks=32, levels=4, moves=0, strip=False),
 }
 # the short legs of the default run: (steps, warm-up, blocks of the model; 0 = all)
-CONFIG_LEGS = {"cfg2": (8, 2, 0), "cfg3": (5, 2, 0), "cfg4": (5, 2, 0), "cfg5": (2, 1, 16)}
+CONFIG_LEGS = {"cfg2": (8, 3, 0), "cfg3": (5, 3, 0), "cfg4": (5, 3, 0), "cfg5": (2, 1, 16)}
 
 
 def parse():
@@ -514,6 +514,8 @@ def main():
     from sleekit_amd import dist as sdist
 
     dev.lazy_errors = True
+    # (measurement knob: which hardware queue a stream lands in follows from how many streams were made before it)
+    _spare = [torch.cuda.Stream() for _ in range(int(os.environ.get("SLK_BENCH_STREAM_OFFSET", "0")))]
     streams = tuple(int(x) for x in args.streams.split(",")) if args.streams else None
     head = Leg(env, args.config or "headline", shapes, levels, moves, strip, streams=streams, distinct=args.distinct)
     L = head.L

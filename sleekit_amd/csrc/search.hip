@@ -30,16 +30,58 @@ __device__ __forceinline__ Best better(Best a, Best b) {
     if (b.v > a.v || (b.v == a.v && b.j < a.j)) return b;
     return a;
 }
+// Cross-lane steps on the vector ALU (DPP) instead of the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32: ~150 cycles
+// each, six dependent levels per reduction, three reductions per move -- a third of a move's time).  A butterfly level only
+// needs SOME lane of the partner group once the earlier levels have made the groups uniform:
+//   xor 1, xor 2: quad_perm;  xor 4: row_half_mirror (lane i <-> 7 - i of each 8);  xor 8: row_mirror (i <-> 15 - i of each 16);
+//   across the four 16-lane rows: v_readlane of lanes 0, 16, 32, 48.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+__device__ __forceinline__ float lane_f(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+
+// sum over the wave in the order of six xor-butterfly levels (1, 2, 4, 8, 16, 32): every lane ends with
+// ((((x + x^1) + ..^2) + ..^4) + ..^8) combined as ((r0 + r1) + (r2 + r3)) over the four rows -- the operands of every addition
+// are those of acc + __shfl_xor(acc, level) (float addition commutes), so the result is that loop's bit for bit
+__device__ __forceinline__ float wave_sum_tree(float acc) {
+    acc = acc + dpp_f<DPP_XOR1>(acc);
+    acc = acc + dpp_f<DPP_XOR2>(acc);
+    acc = acc + dpp_f<DPP_HALF_MIRROR>(acc);
+    acc = acc + dpp_f<DPP_MIRROR>(acc);
+    const float r0 = lane_f(acc, 0), r1 = lane_f(acc, 16), r2 = lane_f(acc, 32), r3 = lane_f(acc, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+
 __device__ __forceinline__ Best wave_best(Best x) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        Best o;
-        o.v = __shfl_xor(x.v, m, 64);
-        o.j = __shfl_xor(x.j, m, 64);
-        o.q = __shfl_xor(x.q, m, 64);
-        x = better(x, o);
+#define SLK_BEST_LEVEL(CTRL)                                                      \
+    {                                                                             \
+        Best o;                                                                   \
+        o.v = dpp_f<CTRL>(x.v);                                                   \
+        o.j = dpp_i<CTRL>(x.j);                                                   \
+        o.q = dpp_f<CTRL>(x.q);                                                   \
+        x = better(x, o);                                                         \
     }
-    return x;
+    SLK_BEST_LEVEL(DPP_XOR1)
+    SLK_BEST_LEVEL(DPP_XOR2)
+    SLK_BEST_LEVEL(DPP_HALF_MIRROR)
+    SLK_BEST_LEVEL(DPP_MIRROR)
+#undef SLK_BEST_LEVEL
+    // the four rows' winners (every lane of a row holds its row's): a total order (value, then column), so any order of
+    // comparisons gives the same winner
+    Best r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        r[k].v = lane_f(x.v, 16 * k);
+        r[k].j = __builtin_amdgcn_readlane(x.j, 16 * k);
+        r[k].q = lane_f(x.q, 16 * k);
+    }
+    return better(better(r[0], r[1]), better(r[2], r[3]));
 }
 
 __global__ void k_extract_diag(PtrTable hs, int n, float *__restrict__ d) {  // blockIdx.y: the layer of a stack
@@ -310,8 +352,7 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
                 }
             }
             // the leaf (8 accumulators = 8 lanes), then the 8 leaves of this register set
-#pragma unroll
-            for (int sh = 1; sh <= 32; sh <<= 1) acc = acc + __shfl_xor(acc, sh, 64);
+            acc = wave_sum_tree(acc);
             if (WAVES > 1 && lane == 0) red_s[s2][wv] = acc;  // this wave's 8 leaves of the set
             total = s2 == 0 ? acc : total + acc;
         }

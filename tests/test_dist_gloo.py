@@ -181,6 +181,16 @@ def _worker_grouped(rank, size, port, q):
         dist.destroy_process_group()
 
 
+def _worker_verify(rank, size, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        q.put((rank, sdist.verify_exchange(make_equal_layers(), FakeBatchBackend(), max_rounds=3)))
+    finally:
+        dist.destroy_process_group()
+
+
 def make_layers_with_a_bad_one():
     layers = make_equal_layers()
     layers[3]["bad"] = 5  # its root (rank 1 of 2) reports a failing pivot: the word travels in the packed factor
@@ -364,3 +374,24 @@ def test_rounds_of_small_layers_in_groups_over_gloo_world2():
         (lo1, hi1), q1, i1 = got[1][3][l]
         assert (lo0, hi1) == (0, R) and hi0 == lo1 and i0 == 0 and i1 == 0
         assert torch.equal(torch.cat([torch.from_numpy(q0), torch.from_numpy(q1)]), single[l]["Q"])
+
+
+@pytest.mark.timeout(120)
+def test_exchange_self_check_over_gloo_world2():
+    """dist.verify_exchange (what `bench.py --gpus N` prints under `rccl`): every rank's copy of every payload carries its
+    root's two checksums, compared across the ranks."""
+    assert sdist.verify_exchange(make_equal_layers(), FakeBatchBackend())["rounds_checked"] == 0  # one rank: nothing crosses
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_verify, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=90) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank in range(2):
+        res = got[rank][1]
+        assert res["agree"] is True and res["rounds_checked"] == 3 and res["world_size"] == 2 and res["backend"] == "gloo"
+        assert res["payload_bytes"] == 8 * (1 + 6 + 36) or res["payload_bytes"] == 8 * (1 + 4 + 16)  # the last round checked

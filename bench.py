@@ -20,7 +20,7 @@ rows of every layer across the ranks (sleekit_amd/dist.py); the factors are made
 xGMI once, in one RCCL all-gather per round of N same-shaped layers.  Total work is the same at every N ("strong").
 
 The ONE JSON line carries the headline run and, unless --no-configs / --config is given, every other BASELINE config
-as a short leg of its own under "configs" (cfg2: 8 steps, cfg3, cfg4: 5; cfg5: 2 steps of 16 of its 32 layers), each with its
+as a short leg of its own under "configs" (cfg2: 20 steps, cfg3, cfg4: 8; cfg5: 2 steps of 16 of its 32 layers; short legs read up to 10 % apart from run to run until the caching allocator has seen a few steps, hence the warm-ups of 6 / 4), each with its
 own roofline and CPU baseline, so that one driver run backs every number of DESIGN.md's table.  Fields besides the contract's:
   roofline      for the kernel with the largest share of the chip's time IN THE TIMED CONFIGURATION (HIP events
                  around every launch, on the launch stream: slk_profile_* in the C ABI; a launch of fewer than 256
@@ -85,7 +85,7 @@ WORKLOADS = {
     "cfg5": dict(name="Llama-FFN 4096x11008 x 32", block=[(4096, 11008)], blocks=32, levels=4, moves=0, strip=False),
 }
 # the short legs of the default run: (steps, warm-up, blocks of the model; 0 = all)
-CONFIG_LEGS = {"cfg2": (8, 3, 0), "cfg3": (5, 3, 0), "cfg4": (5, 3, 0), "cfg5": (2, 1, 16)}
+CONFIG_LEGS = {"cfg2": (20, 6, 0), "cfg3": (8, 4, 0), "cfg4": (8, 4, 0), "cfg5": (2, 1, 16)}
 
 
 def parse():

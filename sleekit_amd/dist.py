@@ -114,8 +114,10 @@ class HipBackend:
             return None, None, None
         if not hasattr(self, "_streams"):
             nf, nl = (self.overlap if isinstance(self.overlap, tuple) else (3, 1))  # best on 8 hardware queues
-            self._streams = ([torch.cuda.Stream() for _ in range(nf)], torch.cuda.Stream(),
-                             [torch.cuda.Stream() for _ in range(nl)])
+            # (SLK_LOOP_PRIORITY / SLK_FACTOR_PRIORITY: measurement knobs, torch stream priorities, -1 = high)
+            lp, fp = int(os.environ.get("SLK_LOOP_PRIORITY", "0")), int(os.environ.get("SLK_FACTOR_PRIORITY", "0"))
+            self._streams = ([torch.cuda.Stream(priority=fp) for _ in range(nf)], torch.cuda.Stream(),
+                             [torch.cuda.Stream(priority=lp) for _ in range(nl)])
         return self._streams
 
     def payload_words(self, n):

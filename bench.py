@@ -20,7 +20,9 @@ rows of every layer across the ranks (sleekit_amd/dist.py); the factors are made
 xGMI once, in one RCCL all-gather per round of N same-shaped layers.  Total work is the same at every N ("strong").
 
 The ONE JSON line carries the headline run and, unless --no-configs / --config is given, every other BASELINE config
-as a short leg of its own under "configs" (cfg2: 20 steps, cfg3, cfg4: 8; cfg5: 2 steps of 16 of its 32 layers; short legs read up to 10 % apart from run to run until the caching allocator has seen a few steps, hence the warm-ups of 6 / 4), each with its
+as a short leg of its own under "configs" (compact: value, ms_per_step, layer_errors {min, max, max_rel_diff_vs_cpu},
+roofline {dominant kernel, its frac timed and alone, loop_frac {alone, timed, timed_chip_time}, top four kernels as [name, chip
+share, frac]}, cpu_baseline) (cfg2: 20 steps, cfg3, cfg4: 8; cfg5: 2 steps of 16 of its 32 layers; short legs read up to 10 % apart from run to run until the caching allocator has seen a few steps, hence the warm-ups of 6 / 4), each with its
 own roofline and CPU baseline, so that one driver run backs every number of DESIGN.md's table.  Fields besides the contract's:
   roofline      for the kernel with the largest share of the chip's time IN THE TIMED CONFIGURATION (HIP events
                  around every launch, on the launch stream: slk_profile_* in the C ABI; a launch of fewer than 256
@@ -481,11 +483,25 @@ def config_leg(env, name):
         if not args.no_profile:
             roofline, exchange, _ = leg.profile(min(steps, 2), full=False)
             dev.raise_pending()
-            out["roofline"] = roofline
+            if roofline:
+                # compact (the one JSON line carries five workloads): the dominant kernel, the loop's three rates, the top four
+                r = roofline
+                loop = r.get("loop") or {}
+                out["roofline"] = {
+                    "kernel": r["kernel"], "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+                    "chip_share": r["share_of_chip_time"], "avg_launch_us": r["avg_launch_us"], "alone_frac": (r.get("alone") or {}).get("frac"),
+                    "chip_time_over_wall": r.get("chip_time_over_wall"),
+                    "loop_frac": {k: (loop.get(k) or {}).get("frac") for k in ("alone", "timed", "timed_chip_time")} if loop else None,
+                    "top": [[k["kernel"], k["chip_share"], k["frac"]] for k in r["top_kernels"][:4]],
+                }
             if exchange:
                 out["exchange"] = {k: round(v, 3) for k, v in exchange.items()}
         if env.rank == 0 and env.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["layer_errors"]["against_cpu"] = leg.cpu_baseline(shards, distinct_shape_sample(shapes), 1)
+            cpu, checks = leg.cpu_baseline(shards, distinct_shape_sample(shapes), 1)
+            cpu["sample"] = cpu["sample"].split("; best of")[0].replace("one layer per distinct shape, weighted by its count in the model: ", "per shape x count: ")
+            out["cpu_baseline"] = cpu
+            out["layer_errors"]["checked_against_cpu"] = len(checks)
+            out["layer_errors"]["max_rel_diff_vs_cpu"] = max(c["rel_diff"] for c in checks)
         return out
     finally:
         leg.release()

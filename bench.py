@@ -181,14 +181,17 @@ class Leg:
         # streams and rounds on them, 14.8 against 15.4)
         few_factors = world >= 4
         # a stream of SMALL layers only (OPT-125M: nothing wider than 3072 columns) is chains of narrow launches in batched
-        # rounds: eight streams, a hardware queue each, overlap them best (4,4: 15.3 ms per step against 19.4 with 3,1 and
-        # 17.3 with 3,3; with 4096-column layers in the stream 3,1 stays ahead: OPT-350M 63.7 against 64.7 / 73.3 ms)
+        # rounds, which go round all the streams: six of them (40 steps after 8 warm-up steps, ms per step: 3,3 14.5-14.6;
+        # 2,4 14.6; 4,4 and 6,6 15.0; 1,1 16.1; no side streams at all 21.1).  With 4096-column layers in the stream 3,1 stays
+        # ahead (OPT-350M 63.7 against 64.7 with 3,3 and 73.3 with 4,2)
         launch_bound = self.widest <= 3072 and world == 1
-        self.streams = streams or ((4, 4) if launch_bound else ((2, 1) if few_factors else (3, 1)))
-        self.backend = sdist.HipBackend(self.cb, "diag", 0.01, moves, with_error=True, overlap=self.streams)
+        self.streams = streams or ((3, 3) if launch_bound else ((2, 1) if few_factors else (3, 1)))
+        # (--streams 0,0: no side streams at all, every kernel of the step in order on the caller's stream)
+        self.backend = sdist.HipBackend(self.cb, "diag", 0.01, moves, with_error=True, overlap=self.streams if sum(self.streams) else False)
         if few_factors:
             self.backend.rounds_on_factor_streams = False
         self.in_flight = []  # per enqueued step: events at the tail of its streams
+        self.host_seconds = 0.0  # spent in quantize_stream (reset by timed())
 
     # -- the step
     def strip_mean(self, lay):
@@ -210,7 +213,9 @@ class Leg:
         # join=False: consecutive steps are independent batches, so the next step's factorisations start under
         # this step's loops (the fence waits for everything before the clock stops); the factorisation statuses of every
         # layer are registered and checked after the timed region (raise_pending)
+        t_host = time.perf_counter()
         shards = sdist.quantize_stream(todo, be or self.backend, join=False)
+        self.host_seconds += time.perf_counter() - t_host  # enqueueing only (nothing in there waits for the GPU)
         # flow control only: the host enqueues a step several times faster than the GPU runs it, and every step in
         # flight holds its own factors and outputs (2-3 GB); never more than four steps ahead
         # (the step's own inputs -- the stripped Hessians of cfg3 are made per step -- stay referenced until the step is
@@ -234,9 +239,11 @@ class Leg:
         for _ in range(n_warm):
             self.step(stream_layers)
         env.fence()
+        self.host_seconds = 0.0
         t0 = time.perf_counter()
         for _ in range(n_steps):
             out = self.step(stream_layers)
+        self.host_ms_per_step = 1e3 * self.host_seconds / n_steps
         env.fence()
         el = time.perf_counter() - t0
         if env.world > 1:
@@ -478,6 +485,7 @@ def config_leg(env, name):
                         + f", {wl['levels']} levels, moves={wl['moves']}{', H - m m^T' if wl['strip'] else ''}",
             "value": round(leg.weights_per_step / (elapsed / steps) / 1e6, 2), "unit": "Mweights/s", "ms_per_step": round(1e3 * elapsed / steps, 3),
             "steps": steps, "warmup": warm, "layers": len(shapes), "setup_seconds": round(leg.t_setup, 1),
+            "host_enqueue_ms_per_step": round(leg.host_ms_per_step, 3),
             "layer_errors": {"layers": len(errs), "all_finite": bool(np.all(np.isfinite(errs))), "min": min(errs), "max": max(errs)},
         }
         if not args.no_profile:
@@ -537,6 +545,7 @@ def main():
     L = head.L
 
     elapsed, shards = head.timed(args.steps, args.warmup)
+    host_ms = head.host_ms_per_step
     dev.raise_pending()  # a Hessian that is not positive definite in any layer of any step: LinAlgError naming the layer
     peak_hbm = torch.cuda.max_memory_reserved(device)  # after the timed region (at most five steps in flight)
     ms_per_step = 1e3 * elapsed / args.steps
@@ -667,6 +676,7 @@ def main():
             "workload": workload, "layers_per_step": L, "distinct_inputs": len(head.made),
             "shapes": sorted({f"{R}x{n}" for R, n in shapes}), "row_sharding": f"{world} ranks",
             "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(head.t_setup, 1),
+            "host_enqueue_ms_per_step": round(host_ms, 3),
             "peak_hbm_gb": round(peak_hbm / 2**30, 2),
             "streams": {"factor": head.streams[0], "loop": head.streams[1]},
             "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),

@@ -32,6 +32,7 @@ always_exchange = False
 # rank's own payload in every slot (the results are meaningless, the work is that of the real rank).
 rehearse = None
 _rehearsal_payloads = {}
+_stream_pool = {}  # device index -> the side streams every HipBackend of this process hands out (HipBackend.streams)
 
 
 class _Done:
@@ -114,10 +115,15 @@ class HipBackend:
             return None, None, None
         if not hasattr(self, "_streams"):
             nf, nl = (self.overlap if isinstance(self.overlap, tuple) else (3, 1))  # best on 8 hardware queues
-            # (SLK_LOOP_PRIORITY / SLK_FACTOR_PRIORITY: measurement knobs, torch stream priorities, -1 = high)
-            lp, fp = int(os.environ.get("SLK_LOOP_PRIORITY", "0")), int(os.environ.get("SLK_FACTOR_PRIORITY", "0"))
-            self._streams = ([torch.cuda.Stream(priority=fp) for _ in range(nf)], torch.cuda.Stream(),
-                             [torch.cuda.Stream(priority=lp) for _ in range(nl)])
+            # ONE set of side streams per device and process, shared by every backend: with 8 hardware queues
+            # (GPU_MAX_HW_QUEUES, sleekit_amd/__init__.py) the first seven streams a process makes -- and the default stream --
+            # have a queue each, later ones double up with them and stop overlapping.  A second backend with streams of its own
+            # ran like a different program (bench.py: OPT-350M 69.8 ms per step after the headline's backend, 61.2 on its streams).
+            dev_index = torch.cuda.current_device()
+            pool = _stream_pool.setdefault(dev_index, [])
+            while len(pool) < nf + nl + 1:
+                pool.append(torch.cuda.Stream())
+            self._streams = (pool[:nf], pool[nf], pool[nf + 1:nf + 1 + nl])
         return self._streams
 
     def payload_words(self, n):

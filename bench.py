@@ -44,6 +44,7 @@ own roofline and CPU baseline, so that one driver run backs every number of DESI
 """
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -236,16 +237,25 @@ class Leg:
 
     def timed(self, n_steps, n_warm, stream_layers=None):
         env = self.env
+        # The host enqueues hundreds of launches per step from Python; a full collection of the cyclic garbage collector in the
+        # middle of that (every object torch and this process ever made: 35-50 ms) is a stall a launch-bound step cannot hide
+        # (one rank of 8 on OPT-125M, 20 steps: 3.5 ms per step, or 5.4-6.3 when a full collection fell into them).  What exists
+        # now is long-lived: collect once, then take it out of the collector's sight (INTEGRATION.md says the same to hosts).
+        gc.collect()
+        gc.freeze()
         for _ in range(n_warm):
             self.step(stream_layers)
         env.fence()
         self.host_seconds = 0.0
+        mallocs = torch.cuda.memory_stats().get("num_device_alloc", 0)
         t0 = time.perf_counter()
         for _ in range(n_steps):
             out = self.step(stream_layers)
         self.host_ms_per_step = 1e3 * self.host_seconds / n_steps
         env.fence()
         el = time.perf_counter() - t0
+        # (a hipMalloc inside the timed region costs tens of ms: the caching allocator had not seen the pipeline at depth yet)
+        self.device_mallocs_while_timed = torch.cuda.memory_stats().get("num_device_alloc", 0) - mallocs
         if env.world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=env.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -486,6 +496,7 @@ def config_leg(env, name):
             "value": round(leg.weights_per_step / (elapsed / steps) / 1e6, 2), "unit": "Mweights/s", "ms_per_step": round(1e3 * elapsed / steps, 3),
             "steps": steps, "warmup": warm, "layers": len(shapes), "setup_seconds": round(leg.t_setup, 1),
             "host_enqueue_ms_per_step": round(leg.host_ms_per_step, 3),
+            "device_mallocs_while_timed": leg.device_mallocs_while_timed,
             "layer_errors": {"layers": len(errs), "all_finite": bool(np.all(np.isfinite(errs))), "min": min(errs), "max": max(errs)},
         }
         if not args.no_profile:
@@ -546,6 +557,7 @@ def main():
 
     elapsed, shards = head.timed(args.steps, args.warmup)
     host_ms = head.host_ms_per_step
+    head_mallocs = head.device_mallocs_while_timed
     dev.raise_pending()  # a Hessian that is not positive definite in any layer of any step: LinAlgError naming the layer
     peak_hbm = torch.cuda.max_memory_reserved(device)  # after the timed region (at most five steps in flight)
     ms_per_step = 1e3 * elapsed / args.steps
@@ -677,6 +689,7 @@ def main():
             "shapes": sorted({f"{R}x{n}" for R, n in shapes}), "row_sharding": f"{world} ranks",
             "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(head.t_setup, 1),
             "host_enqueue_ms_per_step": round(host_ms, 3),
+            "device_mallocs_while_timed": head_mallocs,
             "peak_hbm_gb": round(peak_hbm / 2**30, 2),
             "streams": {"factor": head.streams[0], "loop": head.streams[1]},
             "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),

@@ -118,6 +118,13 @@ int slk_unique_f32(const float *sorted, size_t count, float *out, int *n_out, vo
 int slk_rows_divide(const float *x, const float *scale, int R, int n, int invert, float *out,
                     slk_stream_t stream);
 
+/* The row shards of `batch` layers (host array of device pointers, each to rows x cols contiguous float32) stacked into
+ * dst[batch][rows_padded][cols], the padding rows set to `fill`: what a rank of several does with its rows of a round's
+ * layers before the batch entry points (whole 128-row tiles per layer).  No reference counterpart (the reference has
+ * one layer, all rows: sleekit/obq.py:310-336); one launch per 64 layers instead of a copy per layer.               */
+int slk_stack_rows(const float *const *src, int batch, int rows, int rows_padded, int cols, float fill, float *dst,
+                   slk_stream_t stream);
+
 /* a2  remove_input_bias  (sleekit/obq.py:14-25): out = H - mean mean^T (float32). */
 int slk_hessian_strip_mean(const float *H, const float *mean, int n, float *out,
                            slk_stream_t stream);

@@ -19,15 +19,25 @@ lazy_errors = False
 _pending_info = []
 
 
+_gpu_seen = False
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def require_gpu():
-    if not torch.cuda.is_available():
-        raise RuntimeError(
-            "sleekit_amd needs an AMD GPU (built for gfx950 / MI355X) visible to torch; there is no CPU fallback"
-        )
+    global _gpu_seen
+    if not _gpu_seen:  # (asked once: torch.cuda.is_available() re-reads the environment on every call)
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "sleekit_amd needs an AMD GPU (built for gfx950 / MI355X) visible to torch; there is no CPU fallback"
+            )
+        _gpu_seen = True
     return torch.device("cuda", torch.cuda.current_device())
 
 
 def stream_handle():
+    """The current HIP stream of the current device, as the integer the C-ABI takes (called before every launch)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "slk_workspace_bytes": (c_size_t, [c_int, c_int]),
     "slk_codebook_apply": (c_int, [P, c_size_t, c_int, c_double, c_double, P, c_int, P, P]),
     "slk_rows_divide": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "slk_stack_rows": (c_int, [P, c_int, c_int, c_int, c_int, c_float, P, P]),
     "slk_hessian_strip_mean": (c_int, [P, P, c_int, P, P]),
     "slk_hessian_patch_dead": (c_int, [P, P, c_int, c_int, P, c_size_t, P]),
     "slk_hessian_accumulate": (c_int, [P, P, P, c_int, c_int, c_longlong, P, c_size_t, P]),

@@ -60,6 +60,16 @@ __global__ __launch_bounds__(256) void k_rows_divide(const float *__restrict__ x
     }
 }
 
+// ---------------------------------------------------------------- stacking row shards
+// dst[b][r][:] = src_b[r][:] for r < rows, `fill` for the padding rows up to rows_padded; blockIdx.z = layer
+__global__ __launch_bounds__(256) void k_stack_rows(PtrTable srcs, int rows, int rows_padded, int cols, float fill,
+                                                    float *__restrict__ dst) {
+    const float *__restrict__ src = srcs.p[blockIdx.z];
+    float *__restrict__ out = dst + (size_t)blockIdx.z * rows_padded * cols;
+    const size_t live = (size_t)rows * cols, all = (size_t)rows_padded * cols;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < all; i += (size_t)gridDim.x * 256) out[i] = i < live ? src[i] : fill;
+}
+
 // ---------------------------------------------------------------- H - m m^T
 __global__ __launch_bounds__(256) void k_strip_mean(const float *__restrict__ H,
                                                     const float *__restrict__ mean, int n,
@@ -187,6 +197,24 @@ int slk_rows_divide(const float *x, const float *scale, int R, int n, int invert
     SLK_REQUIRE(x && scale && out, "null pointer");
     hipStream_t s = as_stream(stream);
     SLK_RUN("rows_divide", 0, 8.0 * R * n, s, k_rows_divide<<<stream_blocks(R, 1), 256, 0, s>>>(x, scale, R, n, invert, out));
+    return SLK_OK;
+}
+
+int slk_stack_rows(const float *const *src, int batch, int rows, int rows_padded, int cols, float fill, float *dst,
+                   slk_stream_t stream) {
+    SLK_REQUIRE(batch >= 0 && rows >= 0 && rows_padded >= rows && cols >= 0, "bad shape");
+    if (batch == 0 || rows_padded == 0 || cols == 0) return SLK_OK;
+    SLK_REQUIRE(src && dst, "null pointer");
+    hipStream_t s = as_stream(stream);
+    const size_t per = (size_t)rows_padded * cols;
+    for (int b0 = 0; b0 < batch; b0 += 64) {  // (a table of 64 pointers travels by value with each launch)
+        const int nb = batch - b0 < 64 ? batch - b0 : 64;
+        PtrTable t;
+        for (int b = 0; b < 64; ++b) t.p[b] = b < nb ? src[b0 + b] : nullptr;
+        for (int b = 0; b < nb; ++b) SLK_REQUIRE(t.p[b] || rows == 0, "null source in the batch");
+        const int bx = (int)std::min<size_t>((per + 1023) / 1024, 1024);
+        SLK_RUN("stack_rows", 0, 8.0 * per * nb, s, k_stack_rows<<<dim3(bx, 1, nb), 256, 0, s>>>(t, rows, rows_padded, cols, fill, dst + (size_t)b0 * per));
+    }
     return SLK_OK;
 }
 

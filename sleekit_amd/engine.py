@@ -10,6 +10,8 @@ function `sleekit_amd.obq.quantize_opt` and `sleekit_amd.scaling.quantize_with_s
 wrappers of, and what bench.py times.
 """
 
+import ctypes
+
 import torch
 
 from . import _device as dev
@@ -105,8 +107,6 @@ def factorize_batch(Hs, n, damp, mode):
     """Damping + order + float64 factor of B same-sized float32 device Hessians in launches that cover them all
     (slk_hessian_prepare_batch / slk_chol_inverse_upper_batch).  Returns order (B, n), U (B, n, n), info (B,):
     the results of B calls of factorize."""
-    import ctypes
-
     B = len(Hs)
     device = Hs[0].device
     assert all(H.shape == (n, n) and H.is_contiguous() and H.dtype == torch.float32 for H in Hs)
@@ -182,8 +182,6 @@ def run_loop_batch(W, scale, order, U, cb_abi, min_block, num_blocks, want_idx=T
 def row_errors_batch(W, Q, Hs, symmetric=None):
     """Row errors of a batch of layers stacked by rows: W, Q (B, R, n); Hs a list of B (n, n) float32 tensors.
     symmetric: (B,) int32 verdicts of symmetry_flag (None: checked here)."""
-    import ctypes
-
     B, R, n = W.shape
     assert len(Hs) == B and W.is_contiguous() and Q.is_contiguous()
     assert symmetric is None or (symmetric.dtype == torch.int32 and symmetric.numel() == B and symmetric.is_contiguous())
@@ -226,8 +224,6 @@ def local_search_batch(W, Q, Hs, cb_abi, moves, idx=None, symmetric=None, row_er
     """local_search over a batch of layers stacked by rows: W, Q (B, R, n) (idx (B, R, n) uint8 or None), Hs a list of B
     Hessians; in place on Q and idx, the results of B separate searches.  row_err (B, R) float32: receives the rows' errors
     after the moves, in the domain of W and Q (carried through the search: no product of its own)."""
-    import ctypes
-
     B, R, n = W.shape
     assert len(Hs) == B and W.is_contiguous() and Q.is_contiguous() and (idx is None or idx.is_contiguous())
     levels, lo, hi, table = cb_abi
@@ -237,6 +233,21 @@ def local_search_batch(W, Q, Hs, cb_abi, moves, idx=None, symmetric=None, row_er
         _lib.lib.slk_local_search_batch(dev.ptr(W), dev.ptr(Q), ptrs, B, R, n, levels, lo, hi, dev.ptr(table), int(moves), dev.ptr(idx),
                                         dev.ptr(symmetric), dev.ptr(row_err), dev.ptr(ws), ws_bytes, dev.stream_handle())
     )
+
+
+def stack_rows(parts, rows_padded, fill=0.0):
+    """torch.stack of the layers' row shards (each rows x cols, or rows,) with every layer padded to `rows_padded` rows of
+    `fill`: ONE launch (slk_stack_rows) instead of a copy per layer."""
+    B = len(parts)
+    rows = parts[0].shape[0]
+    cols = parts[0].shape[1] if parts[0].dim() == 2 else 1
+    for t in parts:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != parts[0].shape:
+            raise ValueError("stack_rows wants contiguous float32 shards of one shape")
+    out = torch.empty((B, rows_padded, cols) if parts[0].dim() == 2 else (B, rows_padded), dtype=torch.float32, device=parts[0].device)
+    ptrs = (ctypes.c_void_p * B)(*[dev.ptr(t) for t in parts])
+    _lib.check(_lib.lib.slk_stack_rows(ptrs, B, rows, int(rows_padded), cols, float(fill), dev.ptr(out), dev.stream_handle()))
+    return out
 
 
 def rows_divide(x, scale, invert=False):

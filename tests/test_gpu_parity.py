@@ -1088,6 +1088,28 @@ def test_batch_entry_points(amd, B, R, n, levels):
     assert b"multiple of 64" in amd.lib.lib.slk_last_error()
 
 
+@pytest.mark.parametrize("B,rows,padded,cols", [(1, 96, 128, 768), (48, 96, 128, 768), (70, 5, 128, 33), (3, 128, 128, 1024), (4, 0, 128, 64)])
+def test_stacked_row_shards(amd, B, rows, padded, cols):
+    """slk_stack_rows: the shards of a batch of layers, each its own tensor, padded to whole tiles -- ragged shards, more
+    layers than one pointer table holds, whole tiles, no rows at all; weights (2-D) and scales (1-D)."""
+    g = torch.Generator().manual_seed(B * 1000 + rows)
+    full = [torch.randn((rows + 7, cols), generator=g).cuda() for _ in range(B)]
+    parts = [t[3:3 + rows] for t in full]  # row slices of larger tensors, as dist hands them over
+    out = amd.engine.stack_rows(parts, padded, 0.0)
+    want = torch.zeros((B, padded, cols), device="cuda")
+    for b in range(B):
+        want[b, :rows] = parts[b]
+    assert torch.equal(out, want)
+    scales = [t[3:3 + rows, 0].contiguous() for t in full]
+    out1 = amd.engine.stack_rows(scales, padded, 1.0)
+    want1 = torch.ones((B, padded), device="cuda")
+    for b in range(B):
+        want1[b, :rows] = scales[b]
+    assert torch.equal(out1, want1)
+    with pytest.raises(ValueError):
+        amd.engine.stack_rows([full[0][:, :5]], padded)  # not contiguous
+
+
 @pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 130, 516, 1100])
 def test_symmetry_verdict_at_the_edges(amd, n):
     """The layer error halves its work when H is bit-wise symmetric: a single asymmetric entry anywhere --

@@ -36,6 +36,9 @@ def main():
     for _ in range(2):
         sdist.quantize_stream(layers, backend, join=False)
     torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.freeze()  # (as bench.py: a full collection inside the profile would land on whichever line allocates)
     pr = cProfile.Profile()
     t0 = time.perf_counter()
     pr.enable()
@@ -44,8 +47,8 @@ def main():
         torch.cuda.synchronize()  # the queue never fills: what is timed is the enqueueing
     pr.disable()
     print(f"{cfg} N={N}: {1e3 * (time.perf_counter() - t0) / 3:.2f} ms per step with a synchronize after each")
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
-    pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(30)
 
 
 if __name__ == "__main__":

@@ -109,7 +109,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the single-layer latency, asymmetric-H and Hessian-accumulation legs")
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configs (cfg2 ... cfg5)")
     ap.add_argument("--configs", type=str, default="", help="comma-separated subset of the config legs (default: all four)")
-    ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts (default: 2,1 for 4096-column-and-wider workloads, 3,3 for small-layer models, else 3,1)")
+    ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts of the headline leg (default 3,1; 3,3 for small-layer models)")
     ap.add_argument("--stages", action="store_true", help="also print per-kernel timing table to stderr")
     return ap.parse_args()
 
@@ -186,11 +186,11 @@ class Leg:
         # 2,4 14.6; 4,4 and 6,6 15.0; 1,1 16.1; no side streams at all 21.1).  With 4096-column layers in the stream 3,1 stays
         # ahead (OPT-350M 63.7 against 64.7 with 3,3 and 73.3 with 4,2)
         launch_bound = self.widest <= 3072 and world == 1
-        # nothing narrower than 4096 columns (the headline batch, the 4096 x 11008 layers): two factor streams feed the loop
-        # stream as well as three and leave it more of the chip (three runs each, alternating: 25.50 / 25.52 / 25.48 ms per
-        # step against 25.56 / 25.74 / 25.67; 4096 x 11008: 510 against 517; four or five factor streams 27.6, 3,2 28.2)
-        wide_only = min(n for _, n in shapes) >= 4096
-        self.streams = streams or ((3, 3) if launch_bound else ((2, 1) if few_factors or wide_only else (3, 1)))
+        # (Two factor streams read 0.5 % better for the headline alone -- 25.50 against 25.65 ms per step, alternating runs -- but
+        # the legs that follow in the same process then found the side streams in other roles and hardware queues: OPT-350M
+        # 84 ms per step instead of 61, the single-layer latency 6.6 ms instead of 5.0.  Every one-rank leg therefore keeps
+        # three factor streams in the pool's first three places.)
+        self.streams = streams or ((3, 3) if launch_bound else ((2, 1) if few_factors else (3, 1)))
         # (--streams 0,0: no side streams at all, every kernel of the step in order on the caller's stream)
         self.backend = sdist.HipBackend(self.cb, "diag", 0.01, moves, with_error=True, overlap=self.streams if sum(self.streams) else False)
         if few_factors:

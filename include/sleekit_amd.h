@@ -76,7 +76,9 @@ const char *slk_last_error(void);
  * "no_error_splitk", "error_cb", "no_sym_error", "no_bf16_error", "no_bf16_dma", "no_bf16_hessian", "no_bf16_asym", "no_sym_average",
  * "error_f32_below", "no_wave_search", "lookahead" (EVERY factorisation forks the bulk of its outer updates onto a helper stream: a measurement
  * switch; one call at a time asks for it through slk_chol_inverse_upper_lookahead instead), "window_rows" (16 or 32 rows per
- * window workgroup, forced; 0 = 32, or 16 under SLK_LOOP_LATENCY) (case-insensitive,
+ * window workgroup, forced; 0 = 32, or 16 under SLK_LOOP_LATENCY), "panel_split" (the factorisation's panel step: 1 = two launches, diagonal tile then
+ * the rest, 2 = one launch in which every workgroup below the diagonal tile repeats its pivot chain; 0 = two for batches and from 8192
+ * columns up, one otherwise and always in the look-ahead form) (case-insensitive,
  * an "SLK_" prefix is accepted).  Initial values are read ONCE from the environment (SLK_NO_WINDOW2=1 ...);
  * afterwards only these calls change them.  Process-wide, thread-safe; no reference counterpart.              */
 int slk_set_option(const char *name, int value);

@@ -380,6 +380,117 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
     if (timing && lane == 0) g_panel_cycles[15] += 1;
 }
 
+// The panel step in TWO launches (the default when several layers are in flight): k_chol_panel with ONE workgroup per matrix
+// factors and inverts the diagonal tile (X), then this kernel does what the tiles below it need -- the previous panel's
+// update of the own tile, L21 = A21 inv(L11)^T -- and, in the same grid, the previous panel's update of the tile columns
+// right of this panel (part B of k_chol_panel).  In the one-launch form every workgroup below repeats the diagonal tile's
+// pivot chain to spare a launch: right for ONE factorisation alone on the GPU (the launch chain is its critical path), but
+// `below` workgroups then hold a CU each (135 KB of LDS) for the 22 us of a chain they only wait for -- up to 63 CUs of a
+// 4096-column factor, 171 of an 11008-column one, a quarter to two thirds of the chip that the wide kernels of the other
+// layers could not use.  Here they hold it for the few us of their own work.  Same blocks, same products in the same
+// order, X read back as it was written: the factor is the same bit for bit.
+struct BelowSmem {
+    double a21[PANEL][TP];  // this workgroup's tile of A21
+    double lb[PANEL][TP];   // the previous panel's L of this workgroup's rows
+    double x[PANEL][TP];    // the previous panel's L of the diagonal tile's rows, then inv(L11)
+};
+__global__ __launch_bounds__(256) void k_panel_below(double *__restrict__ A, int ld, int k0, int kprev, int nb, int rest_cols,
+                                                     const double *__restrict__ X) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    A += (size_t)blockIdx.z * ld * ld;
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x >= nb) {  // part B, as in k_chol_panel
+        Tile64Smem &ts = *reinterpret_cast<Tile64Smem *>(smem_raw);
+        const int nt = ld / TILE, tj0 = k0 / TILE + 1;
+        int idx = (int)blockIdx.x - nb, bj = tj0;
+        for (int c = 0; c < rest_cols; ++c, ++bj) {
+            const int count = nt - bj;
+            if (idx < count) break;
+            idx -= count;
+        }
+        const int bi = bj + idx;
+        if (bj >= tj0 + rest_cols || bi >= nt) return;
+        Acc64 acc;
+        acc.zero();
+        const double *pa = A + ((size_t)bi * TILE + (t >> 2)) * ld + (t & 3) * 8;
+        const double *pb = A + ((size_t)bj * TILE + (t >> 2)) * ld + (t & 3) * 8;
+        double *pc = A + (size_t)bi * TILE * ld + (size_t)bj * TILE;
+        Acc64 old;
+        tile64_map(old, [&](int r, int c) { return pc[(size_t)r * ld + c]; });
+        tile64_mac<false>(
+            acc, ts, kprev, kprev + PANEL, [&](int k, double(&v)[8]) { load8d<true>(pa + k, v); },
+            [&](int k, double(&v)[8]) { load8d<true>(pb + k, v); });
+        tile64_foreach2(old, acc, [&](int r, int c, double o, double v) { pc[(size_t)r * ld + c] = o - v; });
+        return;
+    }
+    BelowSmem &sm = *reinterpret_cast<BelowSmem *>(smem_raw);
+    X += (size_t)blockIdx.z * ld * ld;
+    const int lane = t & 63, wave = t >> 6;
+    const bool has_prev = kprev >= 0;
+    const int r0 = k0 + PANEL * ((int)blockIdx.x + 1);
+    const int sr = t >> 2, sc8 = (t & 3) * 16;  // a thread carries 16 consecutive doubles of one row of every tile
+    double vx[16];
+    {
+        double vt[16], vk[16], vb[16];
+        const double *pt = A + (size_t)(r0 + sr) * ld + k0 + sc8;
+        load8d<true>(pt, *reinterpret_cast<double(*)[8]>(&vt[0]));
+        load8d<true>(pt + 8, *reinterpret_cast<double(*)[8]>(&vt[8]));
+        if (has_prev) {
+            const double *pk = A + (size_t)(k0 + sr) * ld + kprev + sc8;
+            load8d<true>(pk, *reinterpret_cast<double(*)[8]>(&vk[0]));
+            load8d<true>(pk + 8, *reinterpret_cast<double(*)[8]>(&vk[8]));
+            const double *pl = A + (size_t)(r0 + sr) * ld + kprev + sc8;
+            load8d<true>(pl, *reinterpret_cast<double(*)[8]>(&vb[0]));
+            load8d<true>(pl + 8, *reinterpret_cast<double(*)[8]>(&vb[8]));
+        }
+        const double *px = X + (size_t)(k0 + sr) * ld + k0 + sc8;
+        load8d<true>(px, *reinterpret_cast<double(*)[8]>(&vx[0]));
+        load8d<true>(px + 8, *reinterpret_cast<double(*)[8]>(&vx[8]));
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            *reinterpret_cast<double2_t *>(&sm.a21[sr][sc8 + e]) = (double2_t){vt[e], vt[e + 1]};
+            if (has_prev) {
+                *reinterpret_cast<double2_t *>(&sm.x[sr][sc8 + e]) = (double2_t){vk[e], vk[e + 1]};
+                *reinterpret_cast<double2_t *>(&sm.lb[sr][sc8 + e]) = (double2_t){vb[e], vb[e + 1]};
+            } else {
+                *reinterpret_cast<double2_t *>(&sm.x[sr][sc8 + e]) = (double2_t){vx[e], vx[e + 1]};
+            }
+        }
+    }
+    __syncthreads();
+    if (has_prev) {
+        // the previous panel's update of the own tile: C -= L_rows L_diag^T, K = 64, accumulated from zero over ascending k
+        // and subtracted once (k_chol_panel's block_syrk); the 16 blocks over the four waves
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if ((i & 3) != wave) continue;
+            const int rb = i >> 2, cb = i & 3;
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) acc = blk_mma_abt(&sm.lb[16 * rb][16 * kq], &sm.x[16 * cb][16 * kq], acc, 1.0, lane);
+            double *cp = &sm.a21[16 * rb][16 * cb];
+            double4_t o = blk_load_d(cp, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = o[r] - acc[r];
+            blk_store_d(cp, lane, o);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) *reinterpret_cast<double2_t *>(&sm.x[sr][sc8 + e]) = (double2_t){vx[e], vx[e + 1]};
+        __syncthreads();
+    }
+    // L21[rb][cb] = sum_{k <= cb} A21[rb][k] X[cb][k]^T (X11 is lower triangular), straight to memory; wave w: row block w
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k <= cb) acc = blk_mma_abt(&sm.a21[16 * wave][16 * k], &sm.x[16 * cb][16 * k], acc, 1.0, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(size_t)(r0 + 16 * wave + (lane >> 4) + 4 * r) * ld + k0 + 16 * cb + (lane & 15)] = acc[r];
+    }
+}
+
 // C[bi][bj] -= L[bi][ka:kb] * L[bj][ka:kb]^T for tiles bi in [ti0, ti1), bj in [tj0, tj1), bj <= bi.
 __global__ __launch_bounds__(256) void k_syrk_tiles(double *__restrict__ A, int ld, int ti0, int tj0, int ka,
                                                     int kb) {
@@ -523,6 +634,16 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
     Helper helper{};
     const bool lookahead = (want_lookahead || opt(OPT_LOOKAHEAD)) && nt >= LOOKAHEAD_MIN_TILES + OUTER / TILE && nt / (OUTER / TILE) < HELPER_EVENTS / 2;
     if (lookahead) SLK_HIP(helper_for(s, 2 * (nt / (OUTER / TILE) + 1), &helper));  // two events per outer block
+    // The panel step in one launch (this factorisation is alone on the GPU: its launch chain is the critical path) or in two
+    // (others are in flight: the tiles below the diagonal tile must not hold their CUs while its pivot chain runs)
+    // Measured on whole streams (ms per step, one launch against two): batches of small matrices gain (OPT-125M 14.50 -> 14.06,
+    // OPT-350M 61.3 -> 61.0, BLOOM-560M 70.1 -> 69.7) and so do 11008-column factors (512.6 -> 503.8, up to 171 workgroups
+    // below); single 4096-column factors do not (headline 25.45 -> 26.7 with two factor streams, 25.55 with three: the longer
+    // launch chain starves the loop stream; OPT-350M 61.6 -> 64.8 when its 4096-column layers split too).  Hence the rule;
+    // slk_set_option("panel_split", 1 | 2) forces two launches | one.
+    const int sp = opt(OPT_PANEL_SPLIT);
+    const bool split = !want_lookahead && sp != 2 && (sp == 1 || batch > 1 || n >= 8192);
+    if (split) SLK_LDS_OPT_IN(k_panel_below, sizeof(BelowSmem));
     int block = 0, forked = -1;  // forked: the last block whose rest went to the helper and has not been joined
     for (int K0 = 0; K0 < ld; K0 += OUTER) {
         const int K1 = K0 + OUTER < ld ? K0 + OUTER : ld;
@@ -538,11 +659,25 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
             int rest = 0;
             for (int c = 0; c < rest_cols; ++c) rest += nt - (k0 / TILE + 1 + c);
             const double prologue = kprev >= 0 ? (double)below * 2.0 * 64 * 64 * 64 + (double)below * 2.0 * 64 * 64 * 64 : 0.0;  // own + diagonal tile
-            SLK_RUN_W("chol_panel",
-                      Bd * (2.0 / 3.0 * 64 * 64 * 64 + (double)(below - 1) * 64 * 64 * 64 + prologue + (double)rest * 2.0 * 64 * 64 * PANEL),
-                      Bd * (16.0 * below * 64 * 64 + (double)rest * 16.0 * 64 * 64), (below + rest) * batch, s,
-                      k_chol_panel<<<dim3(below + rest, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, k0, kprev, below, rest_cols, X, info,
-                                                                                            opt(OPT_WIN_DBG) & 8));
+            if (split) {
+                // two launches: the diagonal tile by one workgroup per matrix, then the tiles below it (and part B) -- see k_panel_below
+                const double pro1 = kprev >= 0 ? 2.0 * 64 * 64 * 64 : 0.0;
+                SLK_RUN_W("chol_panel", Bd * (2.0 / 3.0 * 64 * 64 * 64 + pro1), Bd * 16.0 * 64 * 64, batch, s,
+                          k_chol_panel<<<dim3(1, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, k0, kprev, 1, 0, X, info, opt(OPT_WIN_DBG) & 8));
+                if (below - 1 + rest > 0) {
+                    SLK_RUN_W("chol_panel_below",
+                              Bd * ((double)(below - 1) * 64 * 64 * 64 + (kprev >= 0 ? (double)(below - 1) * 2.0 * 64 * 64 * 64 : 0.0) +
+                                    (double)rest * 2.0 * 64 * 64 * PANEL),
+                              Bd * (24.0 * (below - 1) * 64 * 64 + (double)rest * 16.0 * 64 * 64), (below - 1 + rest) * batch, s,
+                              k_panel_below<<<dim3(below - 1 + rest, 1, B), 256, sizeof(BelowSmem), s>>>(A, ld, k0, kprev, below - 1, rest_cols, X));
+                }
+            } else {
+                SLK_RUN_W("chol_panel",
+                          Bd * (2.0 / 3.0 * 64 * 64 * 64 + (double)(below - 1) * 64 * 64 * 64 + prologue + (double)rest * 2.0 * 64 * 64 * PANEL),
+                          Bd * (16.0 * below * 64 * 64 + (double)rest * 16.0 * 64 * 64), (below + rest) * batch, s,
+                          k_chol_panel<<<dim3(below + rest, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, k0, kprev, below, rest_cols, X, info,
+                                                                                                opt(OPT_WIN_DBG) & 8));
+            }
         }
         const int t0 = K1 / TILE;
         if (nt > t0) {

@@ -1,1 +1,3 @@
-for w in 4 12 24; do python bench.py --config cfg3 --steps 12 --warmup $w --no-configs --no-extras --no-cpu-baseline --no-profile 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg3 warmup $w', j['value'], j['ms_per_step'], j['config'].get('device_mallocs_while_timed'), j['config'].get('host_enqueue_ms_per_step'))"; done
+mkdir -p gpurun_out/final
+SLK_PANEL_SPLIT=2 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/final/bench_a.json 2>/dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --streams 3,1 > gpurun_out/final/bench_b.json 2>/dev/null

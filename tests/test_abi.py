@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_sizes():
     from sleekit_amd import _lib
 
-    assert _lib.lib.slk_abi_version() == 6
+    assert _lib.lib.slk_abi_version() == 7
     assert _lib.lib.slk_factor_ld(1) == 64 and _lib.lib.slk_factor_ld(64) == 64 and _lib.lib.slk_factor_ld(11008) == 11008
     assert _lib.lib.slk_factor_ld(1100) == 1152
     # 4096 x 4096: two float64 n x n scratch matrices dominate
@@ -78,6 +78,10 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert _lib.lib.slk_factor_workspace_bytes_batch(8, 768) >= 8 * 2 * 768 * 768 * 8
     assert _lib.lib.slk_local_search(8, 8, 8, 4, 4, 8, -1.0, 1.0, None, 1, None, None, None, 2, None, None, 0, None) == _lib.E_ARG
     assert b"gains" in _lib.lib.slk_last_error()
+    # ... with ABI version 7
+    assert _lib.lib.slk_stack_rows(one, 1, 8, 4, 16, 0.0, 8, None) == _lib.E_ARG  # fewer padded rows than rows
+    assert _lib.lib.slk_stack_rows(None, 0, 8, 8, 16, 0.0, None, None) == _lib.OK  # an empty batch is nothing to do
+    assert _lib.lib.slk_set_option(b"panel_split", 0) == _lib.OK and _lib.lib.slk_get_option(b"panel_split") == 0
     with pytest.raises(RuntimeError):
         _lib.check(_lib.E_ARG)
 

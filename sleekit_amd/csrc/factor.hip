@@ -619,10 +619,12 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
         return SLK_E_WS;
     }
     hipStream_t s = as_stream(stream);
-    // Outer blocks of 256 columns, of 512 from 8192 columns up: the outer update then runs at K = 512 (0.49 against 0.63 ms
-    // per 4096-column factor alone) while the inner updates it displaces ride in the panel launches' grids; measured on whole
-    // streams: 4096 columns no difference (5140 against 5160 Mweights/s), 11008 columns +2.5 %.
-    const int OUTER = n >= 8192 ? OUTER_LARGE : OUTER_SMALL;
+    // Outer blocks of 256 columns, of 512 from 4096 columns up: the outer update then runs at K = 512 (0.49 against 0.63 ms
+    // per 4096-column factor alone) while the inner updates it displaces ride in the panel launches' grids.  Measured on whole
+    // streams (alternating runs): the headline batch no difference (25.8 ms per step either way), OPT-350M 60.9 -> 59.3 and
+    // BLOOM-560M 69.65 -> 69.0 (their 4096-column factorisations serve 1024 rows each), 11008 columns +2.5 %; 3072 columns
+    // and fewer: none or a loss (OPT-125M 14.11 -> 14.14 / 14.19 with 512 from 3072 / 2048 columns).
+    const int OUTER = n >= 4096 ? OUTER_LARGE : OUTER_SMALL;
     SLK_LDS_OPT_IN(k_chol_panel, sizeof(PanelSmem));
     SLK_RUN_W("clear_info", 0, 4, 1, s, k_clear_info<<<B, 1, 0, s>>>(info));
 

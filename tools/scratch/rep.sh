@@ -1,4 +1,2 @@
-set -o pipefail
-mkdir -p gpurun_out/final
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 &&
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/final/bench_d.json 2> gpurun_out/final/bench_d.err && echo bench-ok
+python tools/micro_rank_of_n.py 2 4 8 2>/dev/null | grep "N=" | cut -c1-45,150-
+for c in cfg3 cfg4; do python tools/micro_rank_of_n.py 8 --config $c 2>/dev/null | grep "N=" | cut -c1-45,150-; done

@@ -108,6 +108,8 @@ class HipBackend:
         self.local_batch = int(os.environ.get("SLK_LOCAL_BATCH", self.local_batch))            # (measurement knobs)
         self.local_batch_cols = int(os.environ.get("SLK_LOCAL_BATCH_COLS", self.local_batch_cols))
         self.group_rows = int(os.environ.get("SLK_GROUP_ROWS", self.group_rows))
+        self.short_factor_batch = int(os.environ.get("SLK_SHORT_FACTOR_BATCH", self.short_factor_batch))
+        self.short_rows = int(os.environ.get("SLK_SHORT_ROWS", self.short_rows))
 
     def streams(self):
         """(factor streams, comm stream, loop streams), created once; (None, None, None) = everything in order."""
@@ -208,6 +210,14 @@ class HipBackend:
         return out
 
     group_rows = 8192  # stacked (padded) rows a loop batch of small shards may reach
+    # Wide layers of few rows on one rank (the 1024 x 4096 layers of OPT-350M / BLOOM-560M: a 4096-column factorisation
+    # each, for a loop of 1024 rows) go in rounds of `short_rows` stacked rows, and a round's factorisations share ONE launch
+    # chain (factorize_many): the chain of 72 narrow launches is what such a layer costs, and six matrices ride it as well
+    # as one.  OPT-350M 59.5 -> 51.8 ms per step, BLOOM-560M 69.2 -> 61.6 (four per chain and 4096 rows: 52.7 / 62.3; two:
+    # 56.5 / 65.7).  Full-height layers gain nothing from sharing a chain (headline 25.6 ms either way: the chip is full
+    # of their wide kernels), 4096 x 11008 layers lose (506 -> 518).
+    short_factor_batch = 8  # at most this many factorisations per launch chain (1: one by one, on rotating streams)
+    short_rows = 6144
 
     def group_limit(self, layer, rows):
         """How many layers of this shape, `rows` of them on this rank, go through the loop as one batch (0: round by round).
@@ -323,8 +333,8 @@ class HipBackend:
     def run_round_stacked(self, round_layers, factors):
         """All rows of a round's layers from their own factors (order, U, info[, symmetry flag]) made elsewhere on this
         GPU: stacked, then ONE loop / error over all of them."""
-        order = torch.stack([f[0] for f in factors])
-        U = torch.stack([f[1] for f in factors])
+        order = _stack_views([f[0] for f in factors])
+        U = _stack_views([f[1] for f in factors])  # (factors that came out of ONE batched factorisation are a stack already)
         info = torch.cat([f[2] for f in factors])
         known = torch.cat([f[3] for f in factors]) if all(len(f) > 3 for f in factors) else None
         return self._run_stacked(round_layers, 0, round_layers[0]["W"].shape[0], order, U, info, known)
@@ -381,6 +391,18 @@ class HipBackend:
                      info=info[b:b + 1]) for b in range(B)]
 
 
+def _stack_views(tensors):
+    """torch.stack -- or, when the tensors already lie one behind the other in one allocation (slices of a batched result),
+    a view of that allocation: no copy (six 4096-column factors are 0.8 GB)."""
+    t0 = tensors[0]
+    step = t0.numel()
+    base = t0.untyped_storage().data_ptr()
+    if t0.is_contiguous() and all(t.is_contiguous() and t.shape == t0.shape and t.dtype == t0.dtype and t.untyped_storage().data_ptr() == base
+                                  and t.storage_offset() == t0.storage_offset() + i * step for i, t in enumerate(tensors)):
+        return t0.as_strided((len(tensors),) + tuple(t0.shape), (step,) + tuple(t0.stride()))
+    return torch.stack(tensors)
+
+
 class _NullCtx:
     def __enter__(self):
         return self
@@ -408,8 +430,9 @@ def _all_gather_words(payload, size):
 def _quantize_stream_local(layers, small, short, backend, join):
     """One rank, a stream with small or short layers in it (quantize_stream).  `small` layers go in batched rounds by
     shape -- factored AND looped together -- one round after the other on alternating streams (a round is a chain of short
-    launches: two or three in flight fill the gaps); `short` ones (wide, few rows) are factored one by one on the factor
-    streams and looped in stacks; the rest through the usual route."""
+    launches: two or three in flight fill the gaps); `short` ones (wide, few rows) go in rounds whose factorisations share
+    one launch chain on a factor stream (HipBackend.short_factor_batch) and whose rows are looped as one stack; the rest
+    through the usual route."""
     n_layers = len(layers)
     out = [None] * n_layers
     fstreams, _, lstreams = backend.streams()
@@ -445,16 +468,24 @@ def _quantize_stream_local(layers, small, short, backend, join):
                     shards = backend.run_round_local([layers[l] for l in idxs])
             keep(shards, idxs)
     if short:
-        # factorisations rotate over the factor streams, every round's stacked loop goes to the loop stream behind them
+        # a round's factorisations in one launch chain (chains rotate over the factor streams), its stacked loop on the loop
+        # stream behind them
         ls = lstreams[0] if side else None
         rotation = getattr(backend, "_factor_rotation", 0) if side else 0
         for members in _short_rounds(layers, short, backend):
             facs, events = [], []
-            for l in members:
+            fb = max(1, int(getattr(backend, "short_factor_batch", 1)))
+            for i in range(0, len(members), fb):
+                job = members[i:i + fb]
                 fs = fstreams[rotation % len(fstreams)] if side else None
                 rotation += 1
                 with on(fs):
-                    facs.append(backend.factorize(layers[l]))
+                    if len(job) > 1 and hasattr(backend, "factorize_many"):
+                        facs.extend(backend.factorize_many([layers[l] for l in job]))
+                    elif len(job) > 1:
+                        facs.extend(backend.factorize(layers[l]) for l in job)
+                    else:
+                        facs.append(backend.factorize(layers[job[0]]))
                     if side:
                         ev = torch.cuda.Event()
                         ev.record(fs)
@@ -492,7 +523,7 @@ def _short_rounds(layers, short, backend):
         by_shape.setdefault((tuple(layers[l]["W"].shape), layers[l].get("scale") is not None), []).append(l)
     rounds = []
     for (shape, _), members in by_shape.items():
-        per = max(2, min(backend.local_batch, 4096 // max(shape[0], 1)))
+        per = max(2, min(backend.local_batch, int(getattr(backend, "short_rows", 4096)) // max(shape[0], 1)))
         rounds.extend(members[i:i + per] for i in range(0, len(members), per))
     return rounds
 

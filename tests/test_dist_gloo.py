@@ -395,3 +395,20 @@ def test_exchange_self_check_over_gloo_world2():
         res = got[rank][1]
         assert res["agree"] is True and res["rounds_checked"] == 3 and res["world_size"] == 2 and res["backend"] == "gloo"
         assert res["payload_bytes"] == 8 * (1 + 6 + 36) or res["payload_bytes"] == 8 * (1 + 4 + 16)  # the last round checked
+
+
+def test_stack_views_reuses_a_batched_result():
+    """dist._stack_views: slices of one batched result stack as a VIEW of it (no copy); anything else through torch.stack."""
+    from sleekit_amd.dist import _stack_views
+
+    x = torch.arange(24.0).reshape(3, 2, 4)
+    v = _stack_views([x[0], x[1], x[2]])
+    assert v.data_ptr() == x.data_ptr() and torch.equal(v, x)
+    v = _stack_views([x[1], x[2]])
+    assert v.data_ptr() == x[1].data_ptr() and torch.equal(v, x[1:])
+    v = _stack_views([x[0], x[2]])  # not neighbours
+    assert v.data_ptr() != x.data_ptr() and torch.equal(v, torch.stack([x[0], x[2]]))
+    y = torch.arange(8.0).reshape(2, 4)
+    assert torch.equal(_stack_views([x[0], y]), torch.stack([x[0], y]))  # another allocation
+    assert torch.equal(_stack_views([x[:, :, 1], x[:, :, 2]]), torch.stack([x[:, :, 1], x[:, :, 2]]))  # not contiguous
+

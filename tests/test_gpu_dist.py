@@ -100,7 +100,7 @@ def test_small_layers_in_batched_rounds_on_one_rank(moves):
     dev = torch.device("cuda", 0)
     cb = codebook.UniformCodebook(8, -1, 1)
     shapes = [(256, 192), (100, 320), (128, 1100), (256, 192), (100, 320), (256, 192), (64, 2048), (100, 320), (48, 172), (48, 172),
-              (1100, 1600), (1100, 1600), (1100, 1600)]  # the last three: wide with few rows -> factored singly, looped as a stack
+              (1100, 1600), (1100, 1600), (1100, 1600)]  # the last three: wide with few rows -> factored in one launch chain, looped as a stack
     layers = []
     for i, (R, n) in enumerate(shapes):
         L = synth.make_layer(R, n, 3100 + i)

@@ -110,6 +110,8 @@ class HipBackend:
         self.group_rows = int(os.environ.get("SLK_GROUP_ROWS", self.group_rows))
         self.short_factor_batch = int(os.environ.get("SLK_SHORT_FACTOR_BATCH", self.short_factor_batch))
         self.short_rows = int(os.environ.get("SLK_SHORT_ROWS", self.short_rows))
+        self.group_wide_rows = int(os.environ.get("SLK_GROUP_WIDE_ROWS", self.group_wide_rows))
+        self.group_bytes = int(os.environ.get("SLK_GROUP_BYTES", self.group_bytes))
 
     def streams(self):
         """(factor streams, comm stream, loop streams), created once; (None, None, None) = everything in order."""
@@ -210,6 +212,12 @@ class HipBackend:
         return out
 
     group_rows = 8192  # stacked (padded) rows a loop batch of small shards may reach
+    group_bytes = 1 << 32  # ... and the bytes of their stacked factors (24 factors of 4096 columns)
+    # WIDE layers join groups too when a rank's shard of them is this few rows (the 1024 x 4096 layers of OPT-350M /
+    # BLOOM-560M from 4 ranks up): a rank then owes a group several 4096-column factorisations, and they share ONE launch
+    # chain (factorize_many) instead of following one another round by round -- one rank of 8, rehearsed: OPT-350M 12.15 ->
+    # 11.06 ms per step, BLOOM-560M 12.9 -> 11.4; one of 4 on OPT-350M 20.3 -> 17.0.
+    group_wide_rows = 256
     # Wide layers of few rows on one rank (the 1024 x 4096 layers of OPT-350M / BLOOM-560M: a 4096-column factorisation
     # each, for a loop of 1024 rows) go in rounds of `short_rows` stacked rows, and a round's factorisations share ONE launch
     # chain (factorize_many): the chain of 72 narrow launches is what such a layer costs, and six matrices ride it as well
@@ -222,11 +230,15 @@ class HipBackend:
     def group_limit(self, layer, rows):
         """How many layers of this shape, `rows` of them on this rank, go through the loop as one batch (0: round by round).
         Small layers only: their shards are chains of short launches (wants_local_batch), and the stacked factors must fit."""
-        if rows <= 0 or not self.wants_local_batch(layer):
+        if rows <= 0:
             return 0
+        if not self.wants_local_batch(layer):
+            # wide layers whose SHARDS are a few rows: a rank's factorisations of consecutive rounds in one chain (below)
+            if not (self.group_wide_rows and rows <= self.group_wide_rows and self.engine.order_mode_code(self.act_order) in (0, 1)):
+                return 0
         n = layer["H"].shape[0]
         padded = (rows + 127) // 128 * 128
-        return int(min(64, self.group_rows // padded, (1 << 31) // (8 * n * n)))
+        return int(min(64, self.group_rows // padded, self.group_bytes // (8 * n * n)))
 
     def note_statuses(self, infos, layers, defer=False):
         """The status words of the layers' factorisations (0, or 1 + the failing pivot), one per layer of the stream:

@@ -78,6 +78,29 @@ def main():
             assert np.array_equal(sh["idx"].cpu().numpy(), res.idx[lo:hi].cpu().numpy())
             np.testing.assert_allclose(sh["row_err"].cpu().numpy(), err[lo:hi].cpu().numpy(), rtol=1e-5)
             assert int(sh["info"].item()) == 0
+    # WIDE layers with few rows (3200 columns: not "small"; 100-row shards, ragged): they join groups too -- four of them on two
+    # ranks are two rounds, ONE group: each rank factors its two in one launch chain, one all-gather, one stacked loop
+    wide = []
+    for i in range(4):
+        lay = synth.make_layer(200, 3200, 950 + i)
+        wide.append({k: torch.from_numpy(lay[k]).to(device) for k in ("W", "H", "scale")})
+    backend = sdist.HipBackend(cb, "diag", 0.01, 0, with_error=True)
+    assert not backend.wants_local_batch(wide[0]) and backend.group_limit(wide[0], 100) >= 4
+    seen = {"round": [], "many": []}
+    run_round, many = backend.run_round, backend.factorize_many
+    backend.run_round = lambda members, *a: (seen["round"].append(len(members)), run_round(members, *a))[1]
+    backend.factorize_many = lambda ls: (seen["many"].append(len(ls)), many(ls))[1]
+    shards = sdist.quantize_stream(wide, backend)
+    torch.cuda.synchronize()
+    assert seen["round"] == [4] and seen["many"] == [2], (rank, seen)
+    for lay, sh in zip(wide, shards):
+        lo, hi = sh["rows"]
+        res = engine.quantize_layer(lay["W"], lay["H"], cb, lay["scale"])
+        err = engine.row_errors(lay["W"], res.Q, lay["H"])
+        assert np.array_equal(sh["Q"].cpu().numpy(), res.Q[lo:hi].cpu().numpy())
+        assert np.array_equal(sh["idx"].cpu().numpy(), res.idx[lo:hi].cpu().numpy())
+        np.testing.assert_allclose(sh["row_err"].cpu().numpy(), err[lo:hi].cpu().numpy(), rtol=1e-5)
+        assert int(sh["info"].item()) == 0
     # an indefinite Hessian in a batched round: its root's status word travels in the packed factor, and EVERY rank
     # raises LinAlgError naming the layer (reference: np.linalg.cholesky, sleekit/obq.py:49-50)
     bad = [dict(lay) for lay in layers]

@@ -390,12 +390,13 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
 // layers could not use.  Here they hold it for the few us of their own work.  Same blocks, same products in the same
 // order, X read back as it was written: the factor is the same bit for bit.
 struct BelowSmem {
-    double a21[PANEL][TP];  // this workgroup's tile of A21
-    double lb[PANEL][TP];   // the previous panel's L of this workgroup's rows
-    double x[PANEL][TP];    // the previous panel's L of the diagonal tile's rows, then inv(L11)
+    double a21[PANEL][TP];  // this workgroup's current tile of A21
+    double lb[PANEL][TP];   // the previous panel's L of that tile's rows
+    double lk[PANEL][TP];   // the previous panel's L of the diagonal tile's rows
+    double x[PANEL][TP];    // inv(L11)
 };
 __global__ __launch_bounds__(256) void k_panel_below(double *__restrict__ A, int ld, int k0, int kprev, int nb, int rest_cols,
-                                                     const double *__restrict__ X) {
+                                                     const double *__restrict__ X, int tiles_below, int per_wg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     A += (size_t)blockIdx.z * ld * ld;
     const int t = threadIdx.x;
@@ -427,67 +428,77 @@ __global__ __launch_bounds__(256) void k_panel_below(double *__restrict__ A, int
     X += (size_t)blockIdx.z * ld * ld;
     const int lane = t & 63, wave = t >> 6;
     const bool has_prev = kprev >= 0;
-    const int r0 = k0 + PANEL * ((int)blockIdx.x + 1);
     const int sr = t >> 2, sc8 = (t & 3) * 16;  // a thread carries 16 consecutive doubles of one row of every tile
-    double vx[16];
-    {
-        double vt[16], vk[16], vb[16];
+    // This workgroup walks the row tiles first, first + 1, ... (`per_wg` of them): inv(L11) and the previous panel's L of the
+    // diagonal tile's rows are the same for every row tile and are loaded ONCE; the next tile's two operands are in flight
+    // while this one is worked on (a workgroup with one tile spends 4.4 of its 8 us waiting for its 128 KB).
+    const int first = (int)blockIdx.x * per_wg, last = min(first + per_wg, tiles_below);
+    double vt[16], vb[16];
+    auto fetch_tile = [&](int rt) {
+        const int r0 = k0 + PANEL * (rt + 1);
         const double *pt = A + (size_t)(r0 + sr) * ld + k0 + sc8;
         load8d<true>(pt, *reinterpret_cast<double(*)[8]>(&vt[0]));
         load8d<true>(pt + 8, *reinterpret_cast<double(*)[8]>(&vt[8]));
         if (has_prev) {
-            const double *pk = A + (size_t)(k0 + sr) * ld + kprev + sc8;
-            load8d<true>(pk, *reinterpret_cast<double(*)[8]>(&vk[0]));
-            load8d<true>(pk + 8, *reinterpret_cast<double(*)[8]>(&vk[8]));
             const double *pl = A + (size_t)(r0 + sr) * ld + kprev + sc8;
             load8d<true>(pl, *reinterpret_cast<double(*)[8]>(&vb[0]));
             load8d<true>(pl + 8, *reinterpret_cast<double(*)[8]>(&vb[8]));
         }
+    };
+    {
+        double vx[16], vk[16];
         const double *px = X + (size_t)(k0 + sr) * ld + k0 + sc8;
         load8d<true>(px, *reinterpret_cast<double(*)[8]>(&vx[0]));
         load8d<true>(px + 8, *reinterpret_cast<double(*)[8]>(&vx[8]));
+        if (has_prev) {
+            const double *pk = A + (size_t)(k0 + sr) * ld + kprev + sc8;
+            load8d<true>(pk, *reinterpret_cast<double(*)[8]>(&vk[0]));
+            load8d<true>(pk + 8, *reinterpret_cast<double(*)[8]>(&vk[8]));
+        }
+        fetch_tile(first);
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            *reinterpret_cast<double2_t *>(&sm.x[sr][sc8 + e]) = (double2_t){vx[e], vx[e + 1]};
+            if (has_prev) *reinterpret_cast<double2_t *>(&sm.lk[sr][sc8 + e]) = (double2_t){vk[e], vk[e + 1]};
+        }
+    }
+    for (int rt = first; rt < last; ++rt) {
+        const int r0 = k0 + PANEL * (rt + 1);
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
             *reinterpret_cast<double2_t *>(&sm.a21[sr][sc8 + e]) = (double2_t){vt[e], vt[e + 1]};
-            if (has_prev) {
-                *reinterpret_cast<double2_t *>(&sm.x[sr][sc8 + e]) = (double2_t){vk[e], vk[e + 1]};
-                *reinterpret_cast<double2_t *>(&sm.lb[sr][sc8 + e]) = (double2_t){vb[e], vb[e + 1]};
-            } else {
-                *reinterpret_cast<double2_t *>(&sm.x[sr][sc8 + e]) = (double2_t){vx[e], vx[e + 1]};
-            }
+            if (has_prev) *reinterpret_cast<double2_t *>(&sm.lb[sr][sc8 + e]) = (double2_t){vb[e], vb[e + 1]};
         }
-    }
-    __syncthreads();
-    if (has_prev) {
-        // the previous panel's update of the own tile: C -= L_rows L_diag^T, K = 64, accumulated from zero over ascending k
-        // and subtracted once (k_chol_panel's block_syrk); the 16 blocks over the four waves
+        __syncthreads();
+        if (rt + 1 < last) fetch_tile(rt + 1);  // lands during the products below
+        if (has_prev) {
+            // the previous panel's update of the own tile: C -= L_rows L_diag^T, K = 64, accumulated from zero over ascending k
+            // and subtracted once (k_chol_panel's block_syrk); wave w: row block w -- the blocks it multiplies next
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if ((i & 3) != wave) continue;
-            const int rb = i >> 2, cb = i & 3;
+            for (int cb = 0; cb < 4; ++cb) {
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) acc = blk_mma_abt(&sm.lb[16 * wave][16 * kq], &sm.lk[16 * cb][16 * kq], acc, 1.0, lane);
+                double *cp = &sm.a21[16 * wave][16 * cb];
+                double4_t o = blk_load_d(cp, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = o[r] - acc[r];
+                blk_store_d(cp, lane, o);
+            }
+            // (a wave reads back only what it wrote itself: LDS operations of one wave complete in order)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // L21[rb][cb] = sum_{k <= cb} A21[rb][k] X[cb][k]^T (X11 is lower triangular), straight to memory; wave w: row block w
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int kq = 0; kq < 4; ++kq) acc = blk_mma_abt(&sm.lb[16 * rb][16 * kq], &sm.x[16 * cb][16 * kq], acc, 1.0, lane);
-            double *cp = &sm.a21[16 * rb][16 * cb];
-            double4_t o = blk_load_d(cp, lane);
+            for (int k = 0; k < 4; ++k)
+                if (k <= cb) acc = blk_mma_abt(&sm.a21[16 * wave][16 * k], &sm.x[16 * cb][16 * k], acc, 1.0, lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = o[r] - acc[r];
-            blk_store_d(cp, lane, o);
+            for (int r = 0; r < 4; ++r) A[(size_t)(r0 + 16 * wave + (lane >> 4) + 4 * r) * ld + k0 + 16 * cb + (lane & 15)] = acc[r];
         }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) *reinterpret_cast<double2_t *>(&sm.x[sr][sc8 + e]) = (double2_t){vx[e], vx[e + 1]};
-        __syncthreads();
-    }
-    // L21[rb][cb] = sum_{k <= cb} A21[rb][k] X[cb][k]^T (X11 is lower triangular), straight to memory; wave w: row block w
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k <= cb) acc = blk_mma_abt(&sm.a21[16 * wave][16 * k], &sm.x[16 * cb][16 * k], acc, 1.0, lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) A[(size_t)(r0 + 16 * wave + (lane >> 4) + 4 * r) * ld + k0 + 16 * cb + (lane & 15)] = acc[r];
+        if (rt + 1 < last) __syncthreads();  // every wave is through with this tile's images before the next one goes in
     }
 }
 
@@ -667,11 +678,16 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
                 SLK_RUN_W("chol_panel", Bd * (2.0 / 3.0 * 64 * 64 * 64 + pro1), Bd * 16.0 * 64 * 64, batch, s,
                           k_chol_panel<<<dim3(1, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, k0, kprev, 1, 0, X, info, opt(OPT_WIN_DBG) & 8));
                 if (below - 1 + rest > 0) {
+                    // two row tiles per workgroup (inv(L11) and the diagonal rows' L loaded once for both, the second tile's
+                    // operands in flight during the first's products): OPT-350M 51.55 -> 51.25 ms per step, 52.0 with four
+                    const int per_wg = 2;
+                    const int nbw = (below - 1 + per_wg - 1) / per_wg;  // workgroups that walk `per_wg` row tiles each
                     SLK_RUN_W("chol_panel_below",
                               Bd * ((double)(below - 1) * 64 * 64 * 64 + (kprev >= 0 ? (double)(below - 1) * 2.0 * 64 * 64 * 64 : 0.0) +
                                     (double)rest * 2.0 * 64 * 64 * PANEL),
-                              Bd * (24.0 * (below - 1) * 64 * 64 + (double)rest * 16.0 * 64 * 64), (below - 1 + rest) * batch, s,
-                              k_panel_below<<<dim3(below - 1 + rest, 1, B), 256, sizeof(BelowSmem), s>>>(A, ld, k0, kprev, below - 1, rest_cols, X));
+                              Bd * (24.0 * (below - 1) * 64 * 64 + (double)rest * 16.0 * 64 * 64), (nbw + rest) * batch, s,
+                              k_panel_below<<<dim3(nbw + rest, 1, B), 256, sizeof(BelowSmem), s>>>(A, ld, k0, kprev, nbw, rest_cols, X, below - 1,
+                                                                                                  per_wg));
                 }
             } else {
                 SLK_RUN_W("chol_panel",

@@ -486,7 +486,9 @@ def _quantize_stream_local(layers, small, short, backend, join):
         rotation = getattr(backend, "_factor_rotation", 0) if side else 0
         for members in _short_rounds(layers, short, backend):
             facs, events = [], []
-            fb = max(1, int(getattr(backend, "short_factor_batch", 1)))
+            n_ = layers[members[0]]["H"].shape[0]
+            # (a chain of B factorisations holds B x (A, U and two workspace images) of n x n doubles: capped at group_bytes)
+            fb = max(1, min(int(getattr(backend, "short_factor_batch", 1)), int(getattr(backend, "group_bytes", 1 << 32)) // (32 * n_ * n_)))
             for i in range(0, len(members), fb):
                 job = members[i:i + fb]
                 fs = fstreams[rotation % len(fstreams)] if side else None

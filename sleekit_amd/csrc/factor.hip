@@ -666,7 +666,7 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
             // inverse of the diagonal tile; the triangular product below it] in `below` workgroups, and in the same grid what
             // is left of the previous panel's update inside this outer block: the tile columns right of this panel (`rest`).
             // (Until round 3 the whole inner update was a launch of its own between two panels: 112 dependent launches per
-            // 4096-column factor, now 64 + 16.)
+            // 4096-column factor, now 64 + 16 -- 64 + 8 with outer blocks of 512 columns.)
             const int kprev = k0 > K0 ? k0 - PANEL : -1;
             const int rest_cols = kprev >= 0 ? (K1 - k0) / PANEL - 1 : 0;
             int rest = 0;

@@ -2,7 +2,9 @@
 """Headline benchmark: Mweights/s quantized (GPTQ 3-bit, 4096 x 4096 layers) on N MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--no-configs]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; started WITHOUT a launcher
+     -- no WORLD_SIZE in the environment -- `bench.py --gpus N` starts that command itself as a child process, before it touches
+     the GPU, relays rank 0's line and exits with the child's code)
 
 One STEP = one pass of the hot path over a batch of synthetic layers, every layer with inputs of its own:
     default   8 layers 4096 x 4096, 3-bit uniform codebook, act_order="diag", damp=0.01, no local search
@@ -22,8 +24,13 @@ xGMI once, in one RCCL all-gather per round of N same-shaped layers.  Total work
 The ONE JSON line carries the headline run and, unless --no-configs / --config is given, every other BASELINE config
 as a short leg of its own under "configs" (compact: value, ms_per_step, layer_errors {min, max, max_rel_diff_vs_cpu},
 roofline {dominant kernel, its frac timed and alone, loop_frac {alone, timed, timed_chip_time}, top four kernels as [name, chip
-share, frac]}, cpu_baseline) (cfg2: 20 steps, cfg3, cfg4: 8; cfg5: 2 steps of 16 of its 32 layers; short legs read up to 10 % apart from run to run until the caching allocator has seen a few steps, hence the warm-ups of 6 / 4), each with its
-own roofline and CPU baseline, so that one driver run backs every number of DESIGN.md's table.  Fields besides the contract's:
+share, frac]}, cpu_baseline) (cfg2: 20 steps, cfg3, cfg4: 8; cfg5: 2 steps of all 32 layers), each with its own roofline and CPU
+baseline, so that one driver run backs every number of DESIGN.md's table.  The line ENDS with "summary": every config's
+[Mweights/s, ms per step], the loop's roofline fractions, the single-layer latency, the Hessian accumulation's fraction and the
+golden-hash checks in under 600 characters -- what a 2 kB tail of the output still holds.  Before a leg's clock starts its pipeline
+runs until the caching allocator has stopped growing (`allocator_settle_steps`, untimed, BEFORE the W warm-up steps): a hipMalloc
+inside the timed steps costs tens of ms; a timed region that still saw one is repeated (`timed_region_repeats`).
+Fields besides the contract's:
   roofline      for the kernel with the largest share of the chip's time IN THE TIMED CONFIGURATION (HIP events
                  around every launch, on the launch stream: slk_profile_* in the C ABI; a launch of fewer than 256
                  workgroups counts for that share of its duration); achieved = ALGORITHMIC flops or bytes of its
@@ -38,6 +45,9 @@ own roofline and CPU baseline, so that one driver run backs every number of DESI
                  weighted by the shape's count in the model;
   layer_errors  the layer error of EVERY layer of the last timed step (all finite), and where the CPU ran the same layer,
                  the relative difference to the oracle's error;
+  golden        layers of the leg whose (shape, seed, levels, moves) tests/golden/large_cases.json holds a hash for, made by the
+                 REAL reference: idx_sha_ok = the indices of the LAST timed step carry that SHA-256 (searched layers: rows whose
+                 hash differs from the reference's, each a proven near-tie in tests/test_gpu_parity.py);
   rccl          (N > 1) what the collective did: world size, backend, bytes a rank receives per step, the exchange's
                  duration measured by events on the comm stream, and whether every rank's copy of the payloads carried its
                  root's checksum (sleekit_amd.dist.verify_exchange).
@@ -88,7 +98,7 @@ WORKLOADS = {
     "cfg5": dict(name="Llama-FFN 4096x11008 x 32", block=[(4096, 11008)], blocks=32, levels=4, moves=0, strip=False),
 }
 # the short legs of the default run: (steps, warm-up, blocks of the model; 0 = all)
-CONFIG_LEGS = {"cfg2": (20, 6, 0), "cfg3": (8, 4, 0), "cfg4": (8, 4, 0), "cfg5": (2, 1, 16)}
+CONFIG_LEGS = {"cfg2": (20, 6, 0), "cfg3": (8, 4, 0), "cfg4": (8, 4, 0), "cfg5": (2, 1, 0)}
 
 
 def parse():
@@ -111,6 +121,8 @@ def parse():
     ap.add_argument("--configs", type=str, default="", help="comma-separated subset of the config legs (default: all four)")
     ap.add_argument("--streams", type=str, default="", help="factor,loop stream counts of the headline leg (default 3,1; 3,3 for small-layer models)")
     ap.add_argument("--stages", action="store_true", help="also print per-kernel timing table to stderr")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="no GPU: the ranks only form a gloo group, all-reduce their ranks and rank 0 prints a line (tests the self-launch)")
     return ap.parse_args()
 
 
@@ -148,7 +160,7 @@ class Env:
 class Leg:
     """One workload on this process group: inputs, backend, the timed loop and its measurements."""
 
-    def __init__(self, env, tag, shapes, levels, moves, strip, streams=None, distinct=0):
+    def __init__(self, env, tag, shapes, levels, moves, strip, streams=None, distinct=0, seeds=None):
         from sleekit_amd import codebook, synth
         from sleekit_amd import dist as sdist
 
@@ -163,17 +175,28 @@ class Leg:
         t0 = time.time()
         distinct = distinct if distinct > 0 else self.L
         self.made, self.layers = {}, []
+        # layer i is made from seed 1000 + i unless the caller names the seeds (tests/test_gpu_timed_path.py)
+        self.seeds = [1000 + (i % distinct) for i in range(self.L)] if seeds is None else list(seeds)
+        assert len(self.seeds) == self.L
         for i, (R, n) in enumerate(shapes):
-            key = (R, n, i % distinct)
+            key = (R, n, self.seeds[i])
             if key not in self.made:
-                lay = synth.make_layer_device(R, n, 1000 + i, env.device)
+                lay = synth.make_layer_device(R, n, self.seeds[i], env.device)
                 self.made[key] = {k: lay[k] for k in ("W", "H", "scale", "mean")}
                 # checked ONCE, here: the synthetic Hessians are bit-wise symmetric (sums of exact products in float64), and
                 # the layer says so -- no symmetry check per step, and a searched layer's error is the one the search carries
                 self.made[key]["symmetric"] = bool(torch.equal(lay["H"], lay["H"].T))
+                if strip:  # ... and so is H - m m^T (m_i m_j commutes): checked on the stripped matrix itself, once, not assumed
+                    Hs = self.strip_mean(self.made[key], check=False)["H"]
+                    self.made[key]["stripped_symmetric"] = bool(torch.equal(Hs, Hs.T))
+                    del Hs
             self.layers.append(self.made[key])
         torch.cuda.synchronize()
         self.t_setup = time.time() - t0
+        # flow control (step): steps in flight hold their factors and outputs -- 8 n^2 bytes of U per layer above all: four
+        # steps ahead for the 4096-column workloads (2-3 GB each), fewer when a step's factors alone are tens of GB (cfg5: 31)
+        step_bytes = sum(8.0 * n * n + 9.0 * R * n for R, n in shapes) / max(world, 1)
+        self.depth = max(1, min(4, int(64e9 / max(step_bytes, 1.0))))
         # (on N > 1 ranks the row shards of a round's N layers go through the loop as one batch: one loop stream; the batched
         # rounds run on the factor streams.  From 4 ranks up a rank factors one or two layers per step: TWO factor streams and
         # the batched rounds on a loop stream of their own measured best -- one rank's step of the headline batch,
@@ -199,15 +222,16 @@ class Leg:
         self.host_seconds = 0.0  # spent in quantize_stream (reset by timed())
 
     # -- the step
-    def strip_mean(self, lay):
-        """a2, remove_input_bias (obq.py:14-25): part of cfg3's path, so inside the step."""
+    def strip_mean(self, lay, check=True):
+        """a2, remove_input_bias (obq.py:14-25): part of cfg3's path, so inside the step.  The derived layer vouches for the
+        symmetry of the STRIPPED Hessian only as far as it was verified on it at setup."""
         from sleekit_amd import _device as dev
         from sleekit_amd import _lib
 
         n = lay["H"].shape[0]
         out = torch.empty_like(lay["H"])
         _lib.check(_lib.lib.slk_hessian_strip_mean(dev.ptr(lay["H"]), dev.ptr(lay["mean"]), n, dev.ptr(out), dev.stream_handle()))
-        return dict(lay, H=out)
+        return dict(lay, H=out, symmetric=bool(lay.get("stripped_symmetric", False)) if check else False)
 
     def step(self, stream_layers=None, be=None):
         from sleekit_amd import dist as sdist
@@ -222,7 +246,7 @@ class Leg:
         shards = sdist.quantize_stream(todo, be or self.backend, join=False)
         self.host_seconds += time.perf_counter() - t_host  # enqueueing only (nothing in there waits for the GPU)
         # flow control only: the host enqueues a step several times faster than the GPU runs it, and every step in
-        # flight holds its own factors and outputs (2-3 GB); never more than four steps ahead
+        # flight holds its own factors and outputs (2-3 GB); never more than self.depth (four) steps ahead
         # (the step's own inputs -- the stripped Hessians of cfg3 are made per step -- stay referenced until the step is
         # through: with join=False the side streams still read them after this returns, and memory handed back to the
         # allocator would be reused by the next step's strip_mean on the current stream)
@@ -234,7 +258,7 @@ class Leg:
                 e.record(st)
                 evs.append(e)
             self.in_flight.append((evs, todo))
-            if len(self.in_flight) > 4:
+            if len(self.in_flight) > self.depth:
                 for e in self.in_flight.pop(0)[0]:
                     e.synchronize()
         return shards
@@ -247,23 +271,51 @@ class Leg:
         # now is long-lived: collect once, then take it out of the collector's sight (INTEGRATION.md says the same to hosts).
         gc.collect()
         gc.freeze()
-        for _ in range(n_warm):
-            self.step(stream_layers)
-        env.fence()
-        self.host_seconds = 0.0
-        mallocs = torch.cuda.memory_stats().get("num_device_alloc", 0)
-        t0 = time.perf_counter()
-        for _ in range(n_steps):
-            out = self.step(stream_layers)
-        self.host_ms_per_step = 1e3 * self.host_seconds / n_steps
-        env.fence()
-        el = time.perf_counter() - t0
-        # (a hipMalloc inside the timed region costs tens of ms: the caching allocator had not seen the pipeline at depth yet)
-        self.device_mallocs_while_timed = torch.cuda.memory_stats().get("num_device_alloc", 0) - mallocs
-        if env.world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=env.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+
+        def device_mallocs():
+            return torch.cuda.memory_stats().get("num_device_alloc", 0)
+
+        # ---- sizing, untimed: the caching allocator keeps a pool per stream and finds new (stream, size) pairs until the
+        #      pipeline has run at its full depth a few times; a hipMalloc costs tens of ms.  The pipeline therefore runs, exactly
+        #      as it will be timed (no fence inside a batch: the steps in flight are what sizes the pools), until a whole batch
+        #      of depth + 1 steps has asked the device for nothing new.  Every rank runs the same number (the slowest decides).
+        self.settle_steps = 0
+        for _ in range(6):
+            before = device_mallocs()
+            for _ in range(self.depth + 1):
+                self.step(stream_layers)
+            self.settle_steps += self.depth + 1
+            grew = device_mallocs() - before
+            if env.world > 1:
+                t = torch.tensor([grew], dtype=torch.int64, device=env.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                grew = int(t.item())
+            if grew == 0:
+                break
+        self.repeats = 0
+        while True:
+            for _ in range(n_warm):
+                self.step(stream_layers)
+            env.fence()
+            self.host_seconds = 0.0
+            mallocs = device_mallocs()
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                out = self.step(stream_layers)
+            self.host_ms_per_step = 1e3 * self.host_seconds / n_steps
+            env.fence()
+            el = time.perf_counter() - t0
+            # (a hipMalloc inside the timed region costs tens of ms: a region that saw one is measured again -- the pools have
+            # grown by what it needed -- at most twice; the count of the region that is REPORTED goes into the line)
+            grew = device_mallocs() - mallocs
+            if env.world > 1:
+                t = torch.tensor([el, float(grew)], dtype=torch.float64, device=env.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el, grew = float(t[0].item()), int(t[1].item())
+            self.device_mallocs_while_timed = grew
+            if grew == 0 or self.repeats >= 2:
+                break
+            self.repeats += 1
         return el, out
 
     # -- measurements
@@ -425,6 +477,52 @@ class Leg:
                 )
         return roofline, exchange, seq
 
+    def golden(self, shards):
+        """Layers of this leg that tests/golden/large_cases.json holds the REAL reference's index hash for (same generator,
+        seed, shape, levels, moves, Hessian treatment): the indices the LAST timed step produced, held to that SHA-256.  A
+        searched layer may differ from it in proven near-tie rows (tests/test_gpu_parity.py proves each one from
+        the reference's move record): there the number of rows whose hash differs from the reference's per-row hashes
+        (tests/golden/ls_traces.npz) is reported instead.  On N > 1 ranks the row shards are gathered on every rank first."""
+        import hashlib
+
+        gdir = os.path.join(ROOT, "tests", "golden")
+        try:
+            cases = json.load(open(os.path.join(gdir, "large_cases.json")))["cases"]
+        except OSError:
+            return None
+        want = {(c["R"], c["n"], c["seed"], c["levels"], c["moves"], bool(c["strip_mean"])): c for c in cases if c["order"] == "diag" and c["damp"] == 0.01}
+        out = []
+        traces = None
+        for i, (R, n) in enumerate(self.shapes):
+            c = want.get((R, n, self.seeds[i], self.levels, self.moves, bool(self.strip)))
+            if c is None or shards[i].get("idx") is None:
+                continue
+            idx = shards[i]["idx"]
+            if self.env.world > 1:  # equal-sized pieces: pad the shard to the tallest one's height
+                tall = -(-R // self.env.world)
+                piece = torch.zeros((tall, n), dtype=torch.uint8, device=idx.device)
+                piece[:idx.shape[0]] = idx
+                parts = [torch.empty_like(piece) for _ in range(self.env.world)]
+                dist.all_gather(parts, piece)
+                from sleekit_amd import dist as sdist
+
+                idx = torch.cat([parts[r][:sdist.row_range(R, r, self.env.world)[1] - sdist.row_range(R, r, self.env.world)[0]] for r in range(self.env.world)])
+            host = idx.cpu().numpy()
+            ok = hashlib.sha256(np.ascontiguousarray(host).tobytes()).hexdigest() == c["sha_idx"]
+            rec = {"layer": i, "shape": f"{R}x{n}", "seed": self.seeds[i], "idx_sha_ok": ok}
+            if not ok and self.moves > 0:
+                try:
+                    traces = traces if traces is not None else np.load(os.path.join(gdir, "ls_traces.npz"))
+                    name = f"r{R}_n{n}_s{self.seeds[i]}_N{self.levels}_diag_ls{self.moves}"
+                    rows = np.array([int.from_bytes(hashlib.sha256(np.ascontiguousarray(r).tobytes()).digest()[:8], "little") for r in host], dtype=np.uint64)
+                    bad = np.flatnonzero(rows != traces[name + "/row_hash"])
+                    rec["rows_differing"] = int(len(bad))
+                    rec["all_recorded_near_ties"] = bool(np.isin(bad, traces[name + "/rows"]).all())
+                except (OSError, KeyError):
+                    pass
+            out.append(rec)
+        return out or None
+
     def cpu_baseline(self, shards, sample_layers, best_of):
         """The oracle on the host cores for `sample_layers` = [(layer index, count in the model)], each timed `best_of` times
         after ONE warm-up of LAPACK / BLAS; rate = weights of the sample (x counts) / its time (x counts).  Where the oracle
@@ -500,8 +598,10 @@ def config_leg(env, name):
             "value": round(leg.weights_per_step / (elapsed / steps) / 1e6, 2), "unit": "Mweights/s", "ms_per_step": round(1e3 * elapsed / steps, 3),
             "steps": steps, "warmup": warm, "layers": len(shapes), "setup_seconds": round(leg.t_setup, 1),
             "host_enqueue_ms_per_step": round(leg.host_ms_per_step, 3),
-            "device_mallocs_while_timed": leg.device_mallocs_while_timed,
+            "device_mallocs_while_timed": leg.device_mallocs_while_timed, "allocator_settle_steps": leg.settle_steps,
+            "timed_region_repeats": leg.repeats,
             "layer_errors": {"layers": len(errs), "all_finite": bool(np.all(np.isfinite(errs))), "min": min(errs), "max": max(errs)},
+            "golden": leg.golden(shards),
         }
         if not args.no_profile:
             roofline, exchange, _ = leg.profile(min(steps, 2), full=False)
@@ -530,8 +630,61 @@ def config_leg(env, name):
         leg.release()
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` without a launcher around it: start `python -m torch.distributed.run --nproc-per-node N bench.py
+    ...` as a CHILD process (this parent has not touched the GPU and never will; never exec), hand rank 0's JSON line on and
+    return the child's exit code."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    last = None
+    for text in child.stdout:  # rank 0 prints ONE JSON line; anything else the ranks say goes to stderr untouched
+        text = text.rstrip("\n")
+        if text.startswith("{") and text.endswith("}"):
+            last = text
+        elif text:
+            print(text, file=sys.stderr, flush=True)
+    rc = child.wait()
+    if last is not None:
+        print(last, flush=True)
+    return rc if rc != 0 or last is not None else 4  # (no line at all is a failure too)
+
+
+def launcher_selftest(args):
+    """The ranks of a (self-)launched job without any GPU work: a gloo group, one all-reduce, one line from rank 0."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        total = int(t.item())
+        dist.destroy_process_group()
+    else:
+        total = 1
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "world_size": world, "gpus_asked": args.gpus, "sum_of_ranks_plus_one": total}), flush=True)
+    return 0 if world == args.gpus else 5
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    if args.launcher_selftest:
+        sys.exit(launcher_selftest(args))
     env = Env(args)
     if args.config:
         wl = dict(WORKLOADS[args.config])
@@ -561,7 +714,7 @@ def main():
 
     elapsed, shards = head.timed(args.steps, args.warmup)
     host_ms = head.host_ms_per_step
-    head_mallocs = head.device_mallocs_while_timed
+    head_mallocs, head_settle, head_repeats = head.device_mallocs_while_timed, head.settle_steps, head.repeats
     dev.raise_pending()  # a Hessian that is not positive definite in any layer of any step: LinAlgError naming the layer
     peak_hbm = torch.cuda.max_memory_reserved(device)  # after the timed region (at most five steps in flight)
     ms_per_step = 1e3 * elapsed / args.steps
@@ -573,6 +726,7 @@ def main():
     layer_errors = {"layers": len(errs), "all_finite": True, "min": min(errs), "max": max(errs)}
     if len(errs) <= 16:
         layer_errors["values"] = errs
+    golden = head.golden(shards)
 
     roofline, exchange = None, None
     if not args.no_profile:
@@ -693,13 +847,13 @@ def main():
             "shapes": sorted({f"{R}x{n}" for R, n in shapes}), "row_sharding": f"{world} ranks",
             "ms_per_layer": round(ms_per_step / L, 3), "setup_seconds": round(head.t_setup, 1),
             "host_enqueue_ms_per_step": round(host_ms, 3),
-            "device_mallocs_while_timed": head_mallocs,
+            "device_mallocs_while_timed": head_mallocs, "allocator_settle_steps": head_settle, "timed_region_repeats": head_repeats,
             "peak_hbm_gb": round(peak_hbm / 2**30, 2),
             "streams": {"factor": head.streams[0], "loop": head.streams[1]},
             "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
         },
         "roofline": roofline, "cpu_baseline": cpu, "layer_error": errs[0], "layer_errors": layer_errors, "latency_ms_single_layer": latency,
-        "asymmetric_H": asym, "hessian_accumulate": hess,
+        "asymmetric_H": asym, "hessian_accumulate": hess, "golden": golden,
     }
     if rccl:
         line["rccl"] = rccl
@@ -709,10 +863,29 @@ def main():
     #      ends the process if the legs take longer than their allowance.
     printed = threading.Event()
 
+    def summary():
+        """What must survive a 2 kB tail of the output: the LAST key of the line, under 600 characters."""
+        loop = (roofline or {}).get("loop") or {}
+        s = {"headline": [round(value, 1), round(ms_per_step, 2)]}
+        for name, leg in (line.get("configs") or {}).items():
+            if isinstance(leg, dict):
+                s[name] = [leg["value"], leg["ms_per_step"]] if "value" in leg else "error"
+        s["loop"] = {k: (loop.get(k) or {}).get("frac") for k in ("alone", "timed")} if loop else None
+        s["latency_ms"] = latency["ms"] if latency else None
+        s["hessian_frac"] = hess["frac"] if hess else None
+        gold = list(golden or []) + [g for leg in (line.get("configs") or {}).values() if isinstance(leg, dict) for g in (leg.get("golden") or [])]
+        s["golden_ok"] = [sum(1 for g in gold if g["idx_sha_ok"] or g.get("all_recorded_near_ties")), len(gold)]
+        s["mallocs_timed"] = [head_mallocs] + [leg.get("device_mallocs_while_timed") for leg in (line.get("configs") or {}).values() if isinstance(leg, dict)]
+        if "error" in (line.get("configs") or {}):
+            s["error"] = line["configs"]["error"][:80]
+        return s
+
     def emit():
         if not printed.is_set():
             printed.set()
             if rank == 0:
+                line.pop("summary", None)
+                line["summary"] = summary()  # last key: the end of the line
                 print(json.dumps(line), flush=True)
 
     if run_configs:
@@ -722,9 +895,12 @@ def main():
         allowance = float(os.environ.get("SLK_BENCH_CONFIGS_SECONDS", "420"))
 
         def bail():
+            # a leg that never came back (on N > 1 ranks: a collective): the headline is printed, and the process ends
+            # NON-ZERO -- the run did not complete
             line["configs"]["error"] = f"config legs exceeded {allowance:.0f} s; stopped"
             emit()
-            os._exit(0)
+            sys.stdout.flush()
+            os._exit(3)
 
         dog = threading.Timer(allowance, bail)
         dog.daemon = True

@@ -11,7 +11,7 @@
  *     matrices are dense row-major; `R` = output rows of W, `n` = input columns;
  *   - `stream` is a hipStream_t passed as void*; calls only enqueue work and never
  *     synchronise, allocate or copy from host memory, so they can be captured
- *     into a hipGraph (sleekit_amd/graphs.py does; zero-fills and copies inside the library are kernels, not
+ *     into a hipGraph (zero-fills and copies inside the library are kernels, not
  *     hipMemsetAsync / hipMemcpyAsync, whose graph nodes did not replay faithfully on ROCm 7.2);
  *   - scratch comes from a caller-provided workspace of at least
  *     slk_workspace_bytes(R, n) bytes, 256-byte aligned; one workspace may be
@@ -188,7 +188,9 @@ int slk_chol_inverse_upper(double *A, int n, double *U, int *info, void *workspa
  *     inside the call: the caller still sees one stream).  Same updates per tile in the same order: U bit for bit.  For
  *     ONE layer at a time (latency); with several factorisations in flight on streams of their own the plain form is
  *     faster.  The helper stream and its events are made at first use per (device, stream) and live until
- *     slk_release_helpers(), which waits for the helpers and destroys them (call it before destroying such a stream).   */
+ *     slk_release_helpers(), which drains BOTH the helper streams and the caller streams they belong to, then destroys
+ *     the helpers (call it before destroying such a stream).  The one call of this library that is not safe beside others:
+ *     no look-ahead factorisation may be enqueued from another thread while it runs.                                        */
 int slk_chol_inverse_upper_lookahead(double *A, int n, double *U, int *info, void *workspace,
                                      size_t ws_bytes, slk_stream_t stream);
 int slk_release_helpers(void);

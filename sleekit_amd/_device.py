@@ -17,6 +17,7 @@ _workspaces = {}
 # pending status words can be checked later with `raise_pending()`.
 lazy_errors = False
 _pending_info = []
+PENDING_LIMIT = 1 << 16  # status words kept for raise_pending() (each keeps a 4-byte device tensor alive)
 
 
 _gpu_seen = False
@@ -104,6 +105,12 @@ def note_info(info, what, defer=False):
     still in flight on another stream -- check with raise_pending() after synchronising)."""
     if lazy_errors or defer:
         _pending_info.append((info, what))
+        if len(_pending_info) > PENDING_LIMIT:  # a loop that never calls raise_pending(): bounded, and it hears about it
+            import warnings
+
+            del _pending_info[: len(_pending_info) - PENDING_LIMIT]
+            warnings.warn(f"sleekit_amd: more than {PENDING_LIMIT} unchecked factorisation statuses; the oldest are dropped "
+                          "-- call sleekit_amd._device.raise_pending() after synchronising", RuntimeWarning, stacklevel=2)
         return
     _raise_if_failed(info, what)
 

@@ -259,8 +259,17 @@ static hipError_t release_helpers() {
     hipError_t first = hipSuccess;
     for (auto &kv : g_helpers) {
         HelperRec &r = kv.second;
-        hipError_t e = hipStreamSynchronize(r.h.stream);
+        // The caller's stream (the map key) still waits on this record's join events when a look-ahead factorisation is in
+        // flight: both streams are drained before anything is destroyed.  (Contract, include/sleekit_amd.h: no factorisation
+        // may be ENQUEUED concurrently with this call -- helper_for hands out a copy of the record that this call invalidates.)
+        int now = 0;
+        (void)hipGetDevice(&now);
+        if (now != kv.first.first) (void)hipSetDevice(kv.first.first);
+        hipError_t e = hipStreamSynchronize(kv.first.second);
         if (e != hipSuccess && first == hipSuccess) first = e;
+        e = hipStreamSynchronize(r.h.stream);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+        if (now != kv.first.first) (void)hipSetDevice(now);
         for (int i = 0; i < r.made; ++i) (void)hipEventDestroy(r.h.events[i]);
         (void)hipStreamDestroy(r.h.stream);
         delete[] r.h.events;

@@ -265,6 +265,10 @@ class HipBackend:
 
     def run_rows(self, layer, lo, hi, factor):
         eng = self.engine
+        if hi <= lo:  # fewer rows than ranks: this rank holds none of this layer
+            n, device = layer["W"].shape[1], layer["W"].device
+            return dict(Q=torch.empty((0, n), dtype=torch.float32, device=device), idx=torch.empty((0, n), dtype=torch.uint8, device=device),
+                        row_err=torch.empty(0, dtype=torch.float32, device=device) if self.with_error else None, rows=(lo, hi))
         W = layer["W"][lo:hi].contiguous()
         sc = layer["scale"][lo:hi].contiguous() if layer.get("scale") is not None else None
         # (lookahead = "alone on the GPU": with overlapping streams the loop takes the window kernel's least-chip-time form)
@@ -305,10 +309,13 @@ class HipBackend:
         # (use on one stream is ordered; rounds on other streams have buffers of their own)
         if not hasattr(self, "_ustacks"):
             self._ustacks = {}
-        key = (device.index, dev.stream_handle(), B, n)
+        # (ONE buffer per stream and width, grown to the largest batch seen and sliced: a buffer per batch size pinned up to
+        # 4 GiB for every distinct B, and a shorter last group added a second one)
+        key = (device.index, dev.stream_handle(), n)
         U = self._ustacks.get(key)
-        if U is None:
+        if U is None or U.shape[0] < B:
             U = self._ustacks[key] = torch.zeros((B, n, n), dtype=torch.float64, device=device)
+        U = U[:B]
         import ctypes
 
         order = torch.empty((B, n), dtype=torch.int64, device=device)
@@ -403,6 +410,19 @@ class HipBackend:
                      info=info[b:b + 1]) for b in range(B)]
 
 
+def _guard_inputs(layers, stream):
+    """The caller's tensors of `layers` (W, H, scale, mean) are read on the side stream `stream`: tell the caching allocator,
+    so that a caller who drops them right after a join=False call does not hand memory the side streams still read back for
+    reuse (the allocator then holds the block until `stream` has passed this point)."""
+    if stream is None:
+        return
+    for lay in layers:
+        for key in ("W", "H", "scale", "mean"):
+            t = lay.get(key)
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(stream)
+
+
 def _stack_views(tensors):
     """torch.stack -- or, when the tensors already lie one behind the other in one allocation (slices of a batched result),
     a view of that allocation: no copy (six 4096-column factors are 0.8 GB)."""
@@ -471,6 +491,8 @@ def _quantize_stream_local(layers, small, short, backend, join):
         for i, members in enumerate(rounds):
             st = pool[i % len(pool)]
             idxs = [small[m] for m in members]
+            if not join:
+                _guard_inputs([layers[l] for l in idxs], st)
             with on(st):
                 if len(idxs) == 1:
                     lay = layers[idxs[0]]
@@ -493,6 +515,8 @@ def _quantize_stream_local(layers, small, short, backend, join):
                 job = members[i:i + fb]
                 fs = fstreams[rotation % len(fstreams)] if side else None
                 rotation += 1
+                if not join:
+                    _guard_inputs([layers[l] for l in job], fs)
                 with on(fs):
                     if len(job) > 1 and hasattr(backend, "factorize_many"):
                         facs.extend(backend.factorize_many([layers[l] for l in job]))
@@ -504,6 +528,8 @@ def _quantize_stream_local(layers, small, short, backend, join):
                         ev = torch.cuda.Event()
                         ev.record(fs)
                         events.append(ev)
+            if not join:
+                _guard_inputs([layers[l] for l in members], ls)
             with on(ls):
                 for ev in events:
                     ls.wait_event(ev)
@@ -551,6 +577,10 @@ def quantize_stream(layers, backend, comm_device=None, join=True):
     (`backend.note_status`): HipBackend raises LinAlgError naming the layer, at once when `join` is true and
     sleekit_amd._device.lazy_errors is off (the default), otherwise at `_device.raise_pending()`.  Every rank sees
     every layer's status, so every rank raises.
+
+    join=True ends in ONE blocking device -> host read of the status words (a host synchronisation per call).  join=False
+    blocks nowhere: `_device.raise_pending()` is then REQUIRED, after synchronising, to see the statuses (the list it reads is
+    bounded: _device.PENDING_LIMIT); the inputs may be dropped at once (_guard_inputs).
     """
     out = _quantize_stream(layers, backend, comm_device, join, True)
     note = getattr(backend, "note_statuses", None)
@@ -575,7 +605,10 @@ def _group_rounds(rounds, layers, backend, rank, size):
             continue
         groups.append([g])
         key_now, count = key, len(members)
-        lo, hi = row_range(first["W"].shape[0], rank, size)
+        # The limit must be the SAME on every rank: it decides how many all-gathers there are and how large.  Shard heights
+        # differ by one when R % size != 0 (1030 rows on 8 ranks: 129 / 128, on either side of the 128-row padding), so every
+        # rank asks with the TALLEST shard, rank 0's = ceil(R / size) -- also for a rank that has no rows of the layer at all.
+        lo, hi = row_range(first["W"].shape[0], 0, size)
         limit = int(limit_of(first, hi - lo)) if (limit_of is not None and key is not None) else 0
     return groups
 
@@ -603,8 +636,8 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
     `join` (default): the caller's stream waits for the loop streams before this returns, so the results can
     be used on it at once.  With join=False nothing waits: the NEXT call's factorisations then start under
     this call's loops (a throughput loop over independent batches, bench.py) -- synchronise the device, or
-    the loop streams, before reading the results, and keep the INPUT tensors alive until then: the side streams still
-    read them after the call returns.
+    the loop streams, before reading the results.  The INPUT tensors may be dropped when the call returns: every side
+    stream that reads them is recorded on them (_guard_inputs), so their memory is not reused before those streams pass.
     """
     rank, size = world()
     n_layers = len(layers)
@@ -649,7 +682,11 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
     for members_g in groups:
         own = [l for g in members_g for l in rounds[g] if root[l] == rank]
         if len(members_g) > 1 and len(own) > 1 and hasattr(backend, "factorize_many"):
-            jobs.append(own)
+            # (a chain of B factorisations holds B x (A, U and two workspace images) of n x n doubles: capped like the one-rank
+            # path's chains, _quantize_stream_local)
+            n_ = layers[own[0]]["H"].shape[0]
+            cap = max(1, int(getattr(backend, "group_bytes", 1 << 32)) // (32 * n_ * n_))
+            jobs.extend(own[i:i + cap] for i in range(0, len(own), cap))
         else:
             jobs.extend([l] for l in own)
     first = getattr(backend, "_factor_rotation", 0) if side else 0
@@ -660,6 +697,8 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
         fs = fstreams[(first + k) % len(fstreams)] if side else None
         if side and k < len(fstreams):
             fs.wait_stream(here)
+        if not join:
+            _guard_inputs([layers[l] for l in job], fs)
         with on(fs):
             made = backend.factorize_many([layers[l] for l in job]) if len(job) > 1 else [backend.factorize(layers[job[0]])]
             ev = None
@@ -753,6 +792,8 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
             batched_rounds += 1
             if side:
                 backend._loop_rotation = batched_rounds % len(lstreams)
+            if not join:
+                _guard_inputs([layers[l] for l in members], ls)
             with on(ls):
                 parts, work = gathered[gi][:2]
                 work.wait()  # orders the stream behind the transfer; no host block on GPU
@@ -766,6 +807,8 @@ def _quantize_stream(layers, backend, comm_device=None, join=True, _local=True):
         for l in members:
             layer = layers[l]
             ls = lstreams[l % len(lstreams)] if side else None
+            if not join:
+                _guard_inputs([layer], ls)
             with on(ls):
                 if exchange:
                     parts, work = gathered[gi][:2]

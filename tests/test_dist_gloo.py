@@ -412,3 +412,81 @@ def test_stack_views_reuses_a_batched_result():
     assert torch.equal(_stack_views([x[0], y]), torch.stack([x[0], y]))  # another allocation
     assert torch.equal(_stack_views([x[:, :, 1], x[:, :, 2]]), torch.stack([x[:, :, 1], x[:, :, 2]]))  # not contiguous
 
+
+
+class RowsGroupingBackend(GroupingBackend):
+    """A group limit that depends on the shard height the way HipBackend.group_limit's does (a step at a padding boundary,
+    nothing for a rank without rows): ranks whose shards differ by one row must still agree on the groups."""
+
+    def __init__(self):
+        super().__init__(0)
+
+    def group_limit(self, layer, rows):
+        return 0 if rows <= 0 else (2 if rows > 3 else 6)
+
+
+def make_ragged_small_layers():
+    """Six layers of 7 rows (4 + 3 on two ranks: either side of the stand-in's step) and six of ONE row (rank 1 has none)."""
+    g = torch.Generator().manual_seed(31)
+    layers = []
+    for R, n in [(7, 5)] * 6 + [(1, 4)] * 6:
+        A = torch.randn(n, n, generator=g)
+        layers.append(dict(id=torch.tensor(len(layers)), W=torch.randn(R, n, generator=g), H=(A @ A.T).float()))
+    return layers
+
+
+def _worker_ragged_groups(rank, size, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        layers = make_ragged_small_layers()
+        be = RowsGroupingBackend()
+        shards = sdist.quantize_stream(layers, be)
+        q.put((rank, be.rounds, [(s["rows"], s["Q"].numpy().copy(), int(s["info"].item())) for s in shards]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_group_plan_is_the_same_on_every_rank():
+    """dist._group_rounds with the REAL HipBackend.group_limit: shard heights that differ by one row across the ranks
+    (R % size != 0), on either side of the 128-row padding or of group_wide_rows, and ranks without any row (R < size) --
+    every rank must come to the same groups, or the ranks issue different all-gathers."""
+    be = sdist.HipBackend.__new__(sdist.HipBackend)  # the limits only: no device, no streams
+    from sleekit_amd import engine
+
+    be.engine, be.act_order = engine, "diag"
+    for R, n, size in ((1030, 768, 8), (4, 768, 8), (2050, 768, 8), (258, 768, 2), (2049, 4096, 8), (1025, 1024, 8), (96, 768, 8)):
+        layers = [dict(W=torch.empty(R, n, device="meta"), H=torch.empty(n, n, device="meta")) for _ in range(40)]
+        rounds, _ = sdist.plan_rounds(layers, size)
+        plans = [sdist._group_rounds(rounds, layers, be, rank, size) for rank in range(size)]
+        assert all(p == plans[0] for p in plans), (R, n, size, [len(p) for p in plans])
+        assert sorted(g for grp in plans[0] for g in grp) == list(range(len(rounds)))
+
+
+@pytest.mark.timeout(120)
+def test_ragged_shards_agree_on_groups_over_gloo_world2():
+    """R % size != 0 with a limit that steps between the two shard heights, and R < size (rank 1 holds no row of the
+    one-row layers): both ranks form the same groups -- the run completes instead of hanging in mismatched all-gathers --
+    and the shards are the rows of the unsharded result."""
+    single = sdist.quantize_stream(make_ragged_small_layers(), FakeBackend())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged_groups, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=90) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    # 7-row layers: the tallest shard (4 rows) sets the limit of 2 for BOTH ranks -> three groups of one round each
+    assert got[0][1][:3] == [[0, 1], [2, 3], [4, 5]] and got[1][1][:3] == got[0][1][:3]
+    # one-row layers: limit 6 on both ranks (rank 1 asks with rank 0's height, not its own zero) -> rank 0 runs them as one batch
+    assert got[0][1][3:] == [[6, 7, 8, 9, 10, 11]]
+    for l, layer in enumerate(make_ragged_small_layers()):
+        R = layer["W"].shape[0]
+        (lo0, hi0), q0, i0 = got[0][2][l]
+        (lo1, hi1), q1, i1 = got[1][2][l]
+        assert (lo0, hi1) == (0, R) and hi0 == lo1 and i0 == 0 and i1 == 0
+        assert torch.equal(torch.cat([torch.from_numpy(q0), torch.from_numpy(q1)]), single[l]["Q"])

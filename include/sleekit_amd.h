@@ -36,6 +36,9 @@ extern "C" {
 #define SLK_E_NOT_PD (-2) /* reported through `info`, see slk_chol_inverse_upper     */
 #define SLK_E_HIP (-3)    /* a HIP runtime call or kernel launch failed              */
 #define SLK_E_WS (-4)     /* workspace too small                                     */
+/* value of a factorisation's status word (`info`) when its chain of workgroups lost one another: a hand-off between two
+ * workgroups of one launch was not seen within 2 s (never observed; the wait is bounded so that nothing can hang the GPU) */
+#define SLK_INFO_HANDOFF_TIMEOUT 0x7fffffff
 
 /* Codebooks.  Every entry point that quantizes takes (levels, lo, hi, table):
  *   table == NULL  UniformCodebook(levels, lo, hi)            (sleekit/codebook.py:4-95)

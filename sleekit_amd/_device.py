@@ -115,8 +115,13 @@ def note_info(info, what, defer=False):
     _raise_if_failed(info, what)
 
 
+HANDOFF_TIMEOUT = 0x7FFFFFFF  # SLK_INFO_HANDOFF_TIMEOUT: a workgroup of the factorisation's chain gave up waiting for another
+
+
 def raise_not_pd(code, what):
     """numpy.linalg.LinAlgError, what np.linalg.cholesky raises in the reference (sleekit/obq.py:49-50)."""
+    if code == HANDOFF_TIMEOUT:
+        raise RuntimeError(f"{what}: the factorisation's workgroups lost one another (hand-off timed out after 2 s); results are void")
     raise np.linalg.LinAlgError(f"{what}: Matrix is not positive definite (pivot {code - 1})")
 
 

@@ -502,6 +502,421 @@ __global__ __launch_bounds__(256) void k_panel_below(double *__restrict__ A, int
     }
 }
 
+
+// ===================================================================================================================
+// Round 4: an outer block's panels in ONE launch, with no workgroup that waits while holding the chip.
+//
+// The panel step above is one (or two) launches per 64 columns: 64-72 dependent launches per 4096-column factor, each
+// about 25 us of which 9.4 are the pivot chain itself -- the rest is the launch gap, the staging of operands nobody
+// could fetch earlier, and the previous panel's update; and in the one-launch form every workgroup below the diagonal
+// tile repeats the pivot chain and holds a CU for it.  Here the DIAGONAL block of an outer block (nb <= 8 tiles square)
+// is factored by a CHAIN of nb workgroups, one per tile row, that hand the panels on through flags in memory:
+//
+//   workgroup r owns tile row r of the diagonal block:  L(r, q) for q < r, then the diagonal tile T_r.
+//   It walks q = 0 .. r-1 left-looking, exactly the arithmetic of the panel kernels tile by tile:
+//       C = A(r, q);  for s < q:  C -= L(r, s) L(q, s)^T      (K = 64 from zero, ONE subtraction per panel s: block_syrk)
+//       L(r, q) = C inv(L_qq)^T                               (l21_block)            -- needs X_q, published by workgroup q
+//       T_r -= L(r, q) L(r, q)^T                              (block_syrk on the diagonal tile, kept in registers)
+//   and when L(r, r-1) is in, factors and inverts T_r (the strips of k_chol_panel, unchanged) and publishes X_r.
+//   Everything that does not hang on X_q is done BEFORE it arrives: while workgroup q runs its pivot chain, workgroup r
+//   applies the updates s <= q-1 to the NEXT tile C_{q+1} (registers), so that at its own turn only
+//       [X_{r-1} crosses] -> L(r, r-1) -> T_r update -> pivots -> inverse -> [X_r crosses]
+//   is on the critical path: no launch gap, no staging of anything but X, no update of older panels.
+//   The rows BELOW the diagonal block wait for nobody: one wide launch afterwards (k_chol_rows_below) makes them all,
+//   16 rows per workgroup, the row strip's own L tiles resident in LDS.  Then the outer update, as before.
+//   Per 4096-column factor: 8 x (chain + rows below + outer update) = 22 launches instead of 72; the chain occupies
+//   nb CUs instead of up to 64 (171 at 11008 columns).
+//
+// Hand-offs follow the write-through form of the CDNA4 guide (Guideline 16, R1; MI355X_MICROARCH.md, visibility, table row 1):
+//   producer: every handed-off byte stored `sc1` (buffer stores, aux 16) -> every storing wave `s_waitcnt vmcnt(0)` ->
+//             workgroup barrier -> ONE lane stores the flag (agent-scope relaxed atomic = `sc1` store);
+//   consumer: every wave polls the flag itself (relaxed agent-scope load + s_sleep, bounded by the realtime clock), and
+//             EVERY load of bytes another workgroup of this launch wrote -- and of its own earlier stores -- is an `sc1`
+//             buffer load to registers (L1 is never consulted: no acquire fence needed, none of its 1.7 us).
+//   One workgroup per CU (135 KB of LDS).  Workgroup r waits only for workgroups q < r of its own matrix, which the
+//   dispatcher started before it; should that ever not hold, the spin gives up after 2 s and the status word says so
+//   (SLK_INFO_HANDOFF_TIMEOUT) instead of hanging the GPU.
+// Same blocks, same products in the same order, one rounding per panel update: U is the panel kernels' bit for bit.
+constexpr int INFO_HANDOFF_TIMEOUT = 0x7fffffff;
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+constexpr int AUX_SC1 = 16;
+
+struct GBuf {  // a matrix as a buffer resource: 16-byte accesses at 32-bit byte offsets, write-through / L1-bypassing on demand
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ GBuf(const double *base, size_t bytes)
+        : rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000)) {}
+    template <int AUX>
+    __device__ __forceinline__ double2_t load2(unsigned elem) const {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, elem * 8u, 0, AUX);
+        return (double2_t){__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2])};
+    }
+    template <int AUX>
+    __device__ __forceinline__ void store2(unsigned elem, double2_t x) const {
+        const u32x4_t v = {(unsigned)__double2loint(x[0]), (unsigned)__double2hiint(x[0]), (unsigned)__double2loint(x[1]), (unsigned)__double2hiint(x[1])};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, elem * 8u, 0, AUX);
+    }
+};
+
+__device__ __forceinline__ int flag_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Every wave calls this for itself; true when *p >= want.  false: gave up (2 s on the 100 MHz realtime clock).
+__device__ __forceinline__ bool flag_wait(const int *p, int want) {
+    bool ok = flag_peek(p) >= want;
+    if (!ok) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            __builtin_amdgcn_s_sleep(1);
+            if (flag_peek(p) >= want) {
+                ok = true;
+                break;
+            }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the compiler from hoisting loads above the poll)
+    return ok;
+}
+// after the stores of every wave: drain, meet, ONE lane signals
+__device__ __forceinline__ void flag_publish(int *p, int value) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A 64 x 64 tile between memory and an LDS image of pitch TP, 16 bytes per lane and instruction: load j of thread t covers
+// row 8 j + (t >> 5), doubles 2 (t & 31) .. +1 -- a wave reads two whole rows (2 x 512 contiguous bytes) per instruction.
+struct TileRegs {
+    double2_t v[8];
+};
+template <int AUX>
+__device__ __forceinline__ void tile_fetch(TileRegs &r, const GBuf &g, unsigned elem0, int ld) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = g.load2<AUX>(elem0 + (unsigned)(8 * j + (t >> 5)) * (unsigned)ld + 2u * (t & 31));
+}
+__device__ __forceinline__ void tile_stash(double (*img)[TP], const TileRegs &r) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<double2_t *>(&img[8 * j + (t >> 5)][2 * (t & 31)]) = r.v[j];
+}
+template <int AUX>
+__device__ __forceinline__ void tile_store_from_lds(const GBuf &g, unsigned elem0, int ld, const double (*img)[TP]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        g.store2<AUX>(elem0 + (unsigned)(8 * j + (t >> 5)) * (unsigned)ld + 2u * (t & 31), *reinterpret_cast<const double2_t *>(&img[8 * j + (t >> 5)][2 * (t & 31)]));
+}
+
+// The diagonal tile in sm.t (blocks on and below the diagonal) -> L11 in sm.t, inv(L11) in sm.x (which must come in zeroed):
+// the strips, deferred block updates and inverse blocks of k_chol_panel for a workgroup without rows of its own, instruction
+// for instruction.  All 256 threads; returns (wave 0) the first column with a non-positive pivot, PANEL if none.
+__device__ __forceinline__ int diag_tile_factor(PanelSmem &sm, int lane, int wave) {
+    auto diag_inverse = [&](int kb) {
+        const int c0 = 16 * kb, c = lane & 15;
+        double xv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int u = 0; u < i; ++u) s = __builtin_fma(sm.t[c0 + i][c0 + u], xv[u], s);
+            xv[i] = ((c == i ? 1.0 : 0.0) - s) * sm.rdiag[c0 + i];
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sm.x[c0 + i][c0 + c] = xv[i];
+        }
+    };
+    auto block_owner = [](int rb, int cb) { return cb == 1 ? rb : (rb == 3 && cb == 2 ? 2 : 1); };
+    auto block_update = [&](int rb, int cb, int kb) {
+        double *c = &sm.t[16 * rb][16 * cb];
+        blk_store_d(c, lane, blk_mma_abt(&sm.t[16 * rb][16 * kb], &sm.t[16 * cb][16 * kb], blk_load_d(c, lane), -1.0, lane));
+    };
+    auto x_block = [&](int rb, int cb) {
+        double4_t sacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k >= cb && k < rb) sacc = blk_mma_ab(&sm.t[16 * rb][16 * k], &sm.x[16 * k][16 * cb], sacc, lane);
+        const double4_t z = {0.0, 0.0, 0.0, 0.0};
+        blk_store_d(&sm.x[16 * rb][16 * cb], lane, blk_mma_a_reg(&sm.x[16 * rb][16 * rb], sacc, z, -1.0, lane));
+    };
+    int first_bad = PANEL;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int c0 = 16 * kb;
+        if (wave == 0) {
+            const int row = c0 + lane;
+            const bool live = row < PANEL;
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = live ? sm.t[live ? row : 0][c0 + c] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double piv = readlane_f64(a[j], j);
+                const bool bad = !(piv > 0.0);
+                first_bad = (bad && first_bad == PANEL) ? c0 + j : first_bad;
+                piv = bad ? 1.0 : piv;
+                const double r = rsqrt_newton(piv);
+                const double lj = a[j] * r;
+                a[j] = lj;
+                sm.rdiag[c0 + j] = r;
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) a[c] = __builtin_fma(-lj, readlane_f64(lj, c), a[c]);
+            }
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) sm.t[row][c0 + c] = (c0 + c <= row) ? a[c] : 0.0;
+            }
+        } else if (kb == 0) {
+        } else if (wave == 3) {
+            diag_inverse(kb - 1);
+        } else {
+#pragma unroll
+            for (int rb = kb + 1; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = kb + 1; cb <= rb; ++cb)
+                    if (block_owner(rb, cb) == wave) block_update(rb, cb, kb - 1);
+            if (kb == 3 && wave == 1) x_block(1, 0);
+        }
+        __syncthreads();
+        if (kb < 3) {
+#pragma unroll
+            for (int rb = kb + 1; rb < 4; ++rb)
+                if (block_owner(rb, kb + 1) == wave) block_update(rb, kb + 1, kb);
+            __syncthreads();
+        }
+    }
+    if (wave == 3) diag_inverse(3);
+    else if (wave == 0) x_block(2, 0);
+    else if (wave == 1) x_block(2, 1);
+    __syncthreads();
+    if (wave < 3) x_block(3, wave);
+    __syncthreads();
+    return first_bad;
+}
+
+// flags of one matrix: [0, nt) xready[p] = 1 when inv(L_pp) of panel p is in X; [nt, 2 nt) rowdone[p] = how many L tiles of
+// tile row p (inside its outer block) are in A.  Zeroed by k_clear_info before the factorisation starts.
+__global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, int ld, int K0, int nb, double *__restrict__ Xall,
+                                                    int *__restrict__ info, int *__restrict__ flags_all) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PanelSmem &sm = *reinterpret_cast<PanelSmem *>(smem_raw);
+    // roles of the four images while this workgroup walks its row:  t: L(q', s) operand   x: X_q
+    //                                                                a21: C_q (complete, waits for X_q)   lb: L(r, s) operand, L(r, q)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = blockIdx.x, nt = ld / PANEL, p0 = K0 / PANEL;
+    const size_t mat = (size_t)ld * ld;
+    double *A = Aall + (size_t)blockIdx.z * mat;
+    const GBuf ga(A, mat * sizeof(double)), gx(Xall + (size_t)blockIdx.z * mat, mat * sizeof(double));
+    info += blockIdx.z;
+    int *xready = flags_all + (size_t)blockIdx.z * 2 * nt, *rowdone = xready + nt;
+    const int row0 = K0 + PANEL * r;
+    auto elem = [&](int tr, int tc) { return (unsigned)(K0 + PANEL * tr) * (unsigned)ld + (unsigned)(K0 + PANEL * tc); };  // tile (tr, tc) of the block
+    bool alive = true;  // false once a wait gave up: the workgroup goes on without waiting (finite, results void, status says so)
+
+    // T_r, blocks on and below the diagonal, in registers (D layout): the i-th such block belongs to wave i & 3 (block_syrk's split)
+    double4_t tp[3];
+    {
+        int i = 0;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb <= rb; ++cb, ++i)
+                if ((i & 3) == wave) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int rr = 16 * rb + (lane >> 4) + 4 * j, cc = 16 * cb + (lane & 15);
+                        // (workgroup 0 starts from the lower triangle as k_chol_panel's first panel of a block does)
+                        tp[i >> 2][j] = (r > 0 || cc <= rr) ? A[(size_t)(row0 + rr) * ld + row0 + cc] : 0.0;
+                    }
+                }
+    }
+    // products of one panel's update: dst block (wave's row block, column block cb) -= lb[row block] t[cb]^T, K = 64 from zero
+    auto update_cn = [&](double4_t(&cn)[4]) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) acc = blk_mma_abt(&sm.lb[16 * wave][16 * kq], &sm.t[16 * cb][16 * kq], acc, 1.0, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cn[cb][j] = cn[cb][j] - acc[j];
+        }
+    };
+
+    if (r > 0) {
+        TileRegs ra, rb_;
+        double4_t cn[4];  // C_{q+1} in the making: this wave's row block
+        // C_0 = A(r, 0) as it stands
+        tile_fetch<0>(ra, ga, elem(r, 0), ld);
+        tile_stash(sm.a21, ra);
+        for (int q = 0; q < r; ++q) {
+            const bool more = q + 1 < r;
+            // (1) while workgroup q is in its pivot chain: the updates s < q of the NEXT tile, C_{q+1} = A(r, q+1) - ...
+            if (more) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        cn[cb][j] = A[(size_t)(row0 + 16 * wave + (lane >> 4) + 4 * j) * ld + K0 + PANEL * (q + 1) + 16 * cb + (lane & 15)];
+                if (q > 0) {
+                    alive = alive && flag_wait(&rowdone[p0 + q + 1], 1);
+                    tile_fetch<AUX_SC1>(ra, ga, elem(r, 0), ld);
+                    tile_fetch<AUX_SC1>(rb_, ga, elem(q + 1, 0), ld);
+                }
+                for (int s = 0; s < q; ++s) {
+                    __syncthreads();  // the images' readers of the step before are through
+                    tile_stash(sm.lb, ra);
+                    tile_stash(sm.t, rb_);
+                    __syncthreads();
+                    if (s + 1 < q) {  // the next pair is in flight during the products
+                        if (alive) alive = flag_wait(&rowdone[p0 + q + 1], s + 2);
+                        tile_fetch<AUX_SC1>(ra, ga, elem(r, s + 1), ld);
+                        tile_fetch<AUX_SC1>(rb_, ga, elem(q + 1, s + 1), ld);
+                    }
+                    update_cn(cn);
+                }
+            }
+            // (2) X_q crosses: L(r, q) = C_q inv(L_qq)^T
+            if (alive) alive = flag_wait(&xready[p0 + q], 1);
+            tile_fetch<AUX_SC1>(ra, gx, elem(q, q), ld);
+            __syncthreads();
+            tile_stash(sm.x, ra);
+            __syncthreads();
+            {
+                double4_t lq[4];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k <= cb) acc = blk_mma_abt(&sm.a21[16 * wave][16 * k], &sm.x[16 * cb][16 * k], acc, 1.0, lane);
+                    lq[cb] = acc;
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) blk_store_d(&sm.lb[16 * wave][16 * cb], lane, lq[cb]);
+            }
+            __syncthreads();
+            // L(r, q) to memory (write-through); T_r -= L(r, q) L(r, q)^T meanwhile
+            tile_store_from_lds<AUX_SC1>(ga, elem(r, q), ld, sm.lb);
+            {
+                int i = 0;
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb <= rb; ++cb, ++i)
+                        if ((i & 3) == wave) {
+                            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int kq = 0; kq < 4; ++kq) acc = blk_mma_abt(&sm.lb[16 * rb][16 * kq], &sm.lb[16 * cb][16 * kq], acc, 1.0, lane);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) tp[i >> 2][j] = tp[i >> 2][j] - acc[j];
+                        }
+            }
+            if (more) {
+                // (3) the last update of C_{q+1}: panel q's, with the L(r, q) just made (in lb) and L(q+1, q) from its owner
+                if (alive) alive = flag_wait(&rowdone[p0 + q + 1], q + 1);
+                tile_fetch<AUX_SC1>(rb_, ga, elem(q + 1, q), ld);
+                tile_stash(sm.t, rb_);  // (t's readers finished before the barriers of (2))
+                flag_publish(&rowdone[p0 + r], q + 1);  // (its barrier also closes the stash)
+                update_cn(cn);
+                // C_{q+1} is complete: into a21, each wave its own row block (the only one it reads back)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) blk_store_d(&sm.a21[16 * wave][16 * cb], lane, cn[cb]);
+            } else {
+                flag_publish(&rowdone[p0 + r], q + 1);
+            }
+        }
+        __syncthreads();  // lb's readers (the last T update) are through before the images change roles
+    }
+    // ---- the turn: T_r -> sm.t, factor, invert, publish
+    {
+        int i = 0;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb <= rb; ++cb, ++i)
+                if ((i & 3) == wave) blk_store_d(&sm.t[16 * rb][16 * cb], lane, tp[i >> 2]);
+        for (int e = t; e < PANEL * PANEL; e += 256) sm.x[e >> 6][e & 63] = 0.0;
+    }
+    __syncthreads();
+    const int first_bad = diag_tile_factor(sm, lane, wave);
+    if (t == 0) {
+        int expect = 0;
+        if (!alive) {
+            __hip_atomic_store(info, INFO_HANDOFF_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (first_bad != PANEL) {
+            // (the workgroups factor their tiles one after the other: the first to report is the smallest column)
+            __hip_atomic_compare_exchange_strong(info, &expect, row0 + first_bad + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    tile_store_from_lds<AUX_SC1>(gx, elem(r, r), ld, sm.x);  // exactly zero above the diagonal
+    flag_publish(&xready[p0 + r], 1);
+}
+
+// The rows below an outer block's diagonal block, after k_chol_chain: for every 16-row strip, panel by panel (left-looking,
+// the tile arithmetic of the panel kernels):  C = A(rows, q) - sum_{s < q} L(rows, s) L(q, s)^T  (one subtraction per s),
+// L(rows, q) = C inv(L_qq)^T.  The strip's own L tiles stay in LDS; the 64 x 64 operands L(q, s), X_q stream through one
+// image, the next one in flight during the products.  Wave w owns column block w of the strip's current tile.
+// Measured and dropped (4096 columns, us per launch; this form: 45): two images and two register sets, one barrier per step
+// and operands two steps ahead: 53; the operands straight from L2 into the MFMA's B layout, no image and no barrier between
+// panels: 74 (a wave instruction then touches sixteen 128-byte lines for 512 bytes).  A step is 16 MFMAs per wave for 32 KB
+// staged: with 16 rows per workgroup the kernel runs at the rate of its operand traffic; what it costs the chip (about half
+// of it for 45 us, seven times per 4096-column factor) is what the panel kernels' waiting workgroups cost before.
+struct RowsBelowSmem {
+    double own[8][16][TP];  // L(rows, s), s < nb
+    double bt[PANEL][TP];   // L(q, s) or X_q
+    double c[16][TP];       // C before the triangular product
+};
+__global__ __launch_bounds__(256) void k_chol_rows_below(double *__restrict__ Aall, int ld, int K0, int nb, const double *__restrict__ Xall) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    RowsBelowSmem &sm = *reinterpret_cast<RowsBelowSmem *>(smem_raw);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const size_t mat = (size_t)ld * ld;
+    double *A = Aall + (size_t)blockIdx.z * mat;
+    const GBuf ga(A, mat * sizeof(double)), gx(Xall + (size_t)blockIdx.z * mat, mat * sizeof(double));
+    const int rows0 = K0 + PANEL * nb + 16 * blockIdx.x;
+    auto tile_elem = [&](int tr, int tc) { return (unsigned)(K0 + PANEL * tr) * (unsigned)ld + (unsigned)(K0 + PANEL * tc); };
+    auto load_c = [&](int q) {  // this wave's column block of A(rows, q), D layout
+        const double *p = A + (size_t)(rows0 + (lane >> 4)) * ld + K0 + PANEL * q + 16 * wave + (lane & 15);
+        return (double4_t){p[0], p[(size_t)4 * ld], p[(size_t)8 * ld], p[(size_t)12 * ld]};
+    };
+    TileRegs nx;
+    tile_fetch<0>(nx, gx, tile_elem(0, 0), ld);  // the first operand: X_0
+    double4_t c = load_c(0), cnext = load_c(nb > 1 ? 1 : 0);  // (the tile after next is fetched a whole panel ahead)
+    for (int q = 0; q < nb; ++q) {
+        for (int s = 0; s <= q; ++s) {
+            const bool tri = s == q;  // the triangular product with X_q closes the panel
+            __syncthreads();          // the readers of bt (and of c) are through
+            tile_stash(sm.bt, nx);
+            if (tri) blk_store_d(&sm.c[0][16 * wave], lane, c);
+            __syncthreads();
+            // next operand in flight: L(q, s+1), or X_q, or the next panel's first (L(q+1, 0))
+            if (!tri) {
+                if (s + 1 < q) tile_fetch<0>(nx, ga, tile_elem(q, s + 1), ld);
+                else tile_fetch<0>(nx, gx, tile_elem(q, q), ld);
+            } else if (q + 1 < nb) {
+                tile_fetch<0>(nx, ga, tile_elem(q + 1, 0), ld);
+            }
+            if (!tri) {
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) acc = blk_mma_abt(&sm.own[s][0][16 * kq], &sm.bt[16 * wave][16 * kq], acc, 1.0, lane);
+                c = c - acc;
+            } else {
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k <= wave) acc = blk_mma_abt(&sm.c[0][16 * k], &sm.bt[16 * wave][16 * k], acc, 1.0, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) A[(size_t)(rows0 + (lane >> 4) + 4 * j) * ld + K0 + PANEL * q + 16 * wave + (lane & 15)] = acc[j];
+                blk_store_d(&sm.own[q][0][16 * wave], lane, acc);
+                c = cnext;
+                if (q + 2 < nb) cnext = load_c(q + 2);
+            }
+        }
+    }
+}
+
 // C[bi][bj] -= L[bi][ka:kb] * L[bj][ka:kb]^T for tiles bi in [ti0, ti1), bj in [tj0, tj1), bj <= bi.
 __global__ __launch_bounds__(256) void k_syrk_tiles(double *__restrict__ A, int ld, int ti0, int tj0, int ka,
                                                     int kb) {
@@ -610,7 +1025,12 @@ __global__ __launch_bounds__(256) void k_flip_out(const double *__restrict__ X, 
     }
 }
 
-__global__ void k_clear_info(int *info) { info[blockIdx.x] = 0; }
+// status words and hand-off flags of a (batched) factorisation, zeroed before it starts
+__global__ void k_clear_info(int *info, int *flags, int per_matrix) {
+    if (threadIdx.x == 0) info[blockIdx.x] = 0;
+    if (flags)
+        for (int i = threadIdx.x; i < per_matrix; i += blockDim.x) flags[(size_t)blockIdx.x * per_matrix + i] = 0;
+}
 
 }  // namespace slk
 
@@ -625,7 +1045,8 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
     Arena ws(workspace, ws_bytes);
     double *X = ws.take<double>((size_t)ld * ld * batch);
     double *S = ws.take<double>((size_t)ld * ld * batch);
-    if (!X || !S) {
+    int *flags = ws.take<int>((size_t)batch * 2 * nt);  // k_chol_chain's hand-off words
+    if (!X || !S || !flags) {
         set_error("workspace too small for %d factorisation(s) of %d x %d", batch, n, n);
         return SLK_E_WS;
     }
@@ -637,7 +1058,7 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
     // and fewer: none or a loss (OPT-125M 14.11 -> 14.14 / 14.19 with 512 from 3072 / 2048 columns).
     const int OUTER = n >= 4096 ? OUTER_LARGE : OUTER_SMALL;
     SLK_LDS_OPT_IN(k_chol_panel, sizeof(PanelSmem));
-    SLK_RUN_W("clear_info", 0, 4, 1, s, k_clear_info<<<B, 1, 0, s>>>(info));
+    SLK_RUN_W("clear_info", 0, 4, 1, s, k_clear_info<<<B, 64, 0, s>>>(info, flags, 2 * nt));
 
     // Look-ahead over the outer blocks (below): a helper stream and events.  For ONE factorisation at a time it takes
     // 0.6 ms off a 4096-column layer (6.2 -> 5.6 ms end to end); with several factorisations in flight on streams of
@@ -654,13 +1075,30 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
     // below); single 4096-column factors do not (headline 25.45 -> 26.7 with two factor streams, 25.55 with three: the longer
     // launch chain starves the loop stream; OPT-350M 61.6 -> 64.8 when its 4096-column layers split too).  Hence the rule;
     // slk_set_option("panel_split", 1 | 2) forces two launches | one.
+    // Since round 4 the default is neither: an outer block's panels are ONE launch of a chain of workgroups that hand the
+    // panels on through flags (k_chol_chain), plus one wide launch for the rows below (k_chol_rows_below) -- same U bit for
+    // bit; panel_split = 1 | 2 still force the panel kernels (3 = the chain, explicitly).
     const int sp = opt(OPT_PANEL_SPLIT);
-    const bool split = !want_lookahead && sp != 2 && (sp == 1 || batch > 1 || n >= 8192);
+    const bool chain = sp == 0 || sp == 3;
+    const bool split = !chain && !want_lookahead && sp != 2 && (sp == 1 || batch > 1 || n >= 8192);
     if (split) SLK_LDS_OPT_IN(k_panel_below, sizeof(BelowSmem));
+    if (chain) {
+        SLK_LDS_OPT_IN(k_chol_chain, sizeof(PanelSmem));
+        SLK_LDS_OPT_IN(k_chol_rows_below, sizeof(RowsBelowSmem));
+    }
     int block = 0, forked = -1;  // forked: the last block whose rest went to the helper and has not been joined
     for (int K0 = 0; K0 < ld; K0 += OUTER) {
         const int K1 = K0 + OUTER < ld ? K0 + OUTER : ld;
-        for (int k0 = K0; k0 < K1; k0 += PANEL) {
+        if (chain) {
+            const int nb = (K1 - K0) / PANEL, below_tiles = (ld - K1) / PANEL;
+            const double e = 64.0 * nb;
+            SLK_RUN_W("chol_chain", Bd * e * e * e / 3.0, Bd * 12.0 * e * e, nb * batch, s,
+                      k_chol_chain<<<dim3(nb, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, K0, nb, X, info, flags));
+            if (below_tiles > 0)
+                SLK_RUN_W("chol_rows_below", Bd * 64.0 * below_tiles * e * e, Bd * (16.0 * 64 * below_tiles * e + 4.0 * e * e), 4 * below_tiles * batch, s,
+                          k_chol_rows_below<<<dim3(4 * below_tiles, 1, B), 256, sizeof(RowsBelowSmem), s>>>(A, ld, K0, nb, X));
+        }
+        for (int k0 = K0; k0 < K1 && !chain; k0 += PANEL) {
             const int below = (ld - k0) / PANEL;  // tiles from the diagonal tile down
             // ONE launch per panel: [the previous panel's update of this tile column (prologue of every workgroup); potf2 +
             // inverse of the diagonal tile; the triangular product below it] in `below` workgroups, and in the same grid what
@@ -787,5 +1225,6 @@ extern "C" int slk_probe_panel_cycles(long long *host_out, int reset) {
 extern "C" size_t slk_factor_workspace_bytes_batch(int batch, int n) {
     if (batch < 1 || batch > 64 || n <= 0) return 0;
     const size_t ld = (size_t)slk_factor_ld(n);
-    return 2 * ld * ld * sizeof(double) * batch + (size_t)batch * (64 * sizeof(float) + (size_t)n * (sizeof(double) + sizeof(int))) + (1u << 16);
+    return 2 * ld * ld * sizeof(double) * batch + (size_t)batch * (64 * sizeof(float) + (size_t)n * (sizeof(double) + sizeof(int))) +
+           (size_t)batch * 2 * (ld / 64) * sizeof(int) + (1u << 16);
 }

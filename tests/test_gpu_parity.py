@@ -263,29 +263,35 @@ def test_factor_lookahead_changes_nothing(amd):
     assert torch.equal(U0, U2)
 
 
-@pytest.mark.parametrize("n", [64, 100, 128, 320, 768, 1100, 2048])
+@pytest.mark.parametrize("n", [64, 100, 128, 320, 768, 1100, 2048, 4096, 4700])
 def test_factor_panel_step_in_two_launches_is_the_one_launch_form(amd, n):
-    """The panel step of the factorisation runs as two launches for batches and very wide matrices (diagonal tile by one
-    workgroup, then the tiles below it) and as one otherwise (option panel_split forces either): same blocks, same products,
-    same order -- the same U, order and status bit for bit, one matrix or a batch, positive definite or not."""
+    """Three forms of the factorisation's panel step, one arithmetic: the CHAIN (round 4, the default: an outer block's panels
+    in one launch of workgroups that hand the panels on through flags, then one wide launch for the rows below), the panel
+    kernel in two launches (diagonal tile by one workgroup, then the tiles below it) and in one (option panel_split = 3 | 1 |
+    2): same blocks, same products, same order -- the same U, order and status bit for bit, one matrix or a batch, positive
+    definite or not.  (4096 and 4700 columns: outer blocks of 512 columns = chains of 8 workgroups, a short last block.)"""
     dev_ = torch.device("cuda")
     Hs = [synth.make_layer_device(8, n, 4200 + b, dev_)["H"] for b in range(3)]
     bad = Hs[1].clone()
     bad[n // 2, n // 2] = -1.0  # not positive definite: the status word names the same pivot either way
-    with amd.lib.option("panel_split", 1):
-        two = [amd.engine.factorize(H, n, 0.01, amd.lib.ORDER_DIAG) for H in Hs + [bad]]
-        two_b = amd.engine.factorize_batch(Hs, n, 0.01, amd.lib.ORDER_DIAG)
-    with amd.lib.option("panel_split", 2):
-        one = [amd.engine.factorize(H, n, 0.01, amd.lib.ORDER_DIAG) for H in Hs + [bad]]
-        one_b = amd.engine.factorize_batch(Hs, n, 0.01, amd.lib.ORDER_DIAG)
+    forms = {}
+    for form in (1, 2, 3, 0):
+        with amd.lib.option("panel_split", form):
+            forms[form] = ([amd.engine.factorize(H, n, 0.01, amd.lib.ORDER_DIAG) for H in Hs + [bad]],
+                           amd.engine.factorize_batch(Hs, n, 0.01, amd.lib.ORDER_DIAG),
+                           amd.engine.factorize(Hs[0], n, 0.01, amd.lib.ORDER_DIAG, lookahead=True))
     torch.cuda.synchronize()
-    for (o2, U2, i2), (o1, U1, i1) in zip(two, one):
-        assert torch.equal(o1, o2) and int(i1.item()) == int(i2.item())
-        if int(i1.item()) == 0:
-            assert torch.equal(U1, U2)
+    two, two_b, _ = forms[1]
+    for form in (2, 3, 0):
+        one, one_b, ahead = forms[form]
+        for (o2, U2, i2), (o1, U1, i1) in zip(two, one):
+            assert torch.equal(o1, o2) and int(i1.item()) == int(i2.item()), form
+            if int(i1.item()) == 0:
+                assert torch.equal(U1, U2), form
+        for x, y in zip(two_b, one_b):
+            assert torch.equal(x, y), form
+        assert torch.equal(ahead[1], two[0][1]) and int(ahead[2].item()) == 0, form
     assert int(two[3][2].item()) != 0
-    for x, y in zip(two_b, one_b):
-        assert torch.equal(x, y)
     for b in range(3):
         assert torch.equal(two_b[1][b], two[b][1])
 

@@ -84,7 +84,8 @@ enum Opt {
     OPT_NO_WAVE_SEARCH,        // local search: the workgroup-per-row kernel for every row length
     OPT_LOOKAHEAD,             // factorisation: the bulk of an outer syrk on a helper stream, beside the next block's panels
     OPT_WINDOW_ROWS,           // window kernel: rows per workgroup forced to 16 or 32 (0: 32, or 16 where the caller asks for latency)
-    OPT_PANEL_SPLIT,           // factorisation: the panel step in two launches (1) or one (2) whatever the shape (0: two for batches and from 8192 columns up)
+    OPT_PANEL_SPLIT,           // factorisation: 0 / 3: an outer block's panels as a chain of workgroups in one launch; 1 / 2: the panel kernel, two launches / one per panel
+    OPT_NO_TALL_ERROR,         // layer error: 128 x 128 tiles for whole layers too (default: 256 x 128 from 2048 rows up)
     OPT_COUNT
 };
 int opt(Opt o);

@@ -212,4 +212,100 @@ __device__ __forceinline__ void tile128_mac_dma(Acc128 &acc, TileBf16DmaSmem &sm
     }
 }
 
+// ---- 256 x 128 tiles (round 4).  At 128 x 128 a round moves 48 KB out of L2 per 6.3 Mflop and the MFMA is busy 0.42 of the
+// time (profiles/r03_pmc_mfma.json).  A workgroup of 512 threads (eight waves, each its 64 x 64 sub-tile as before: wave w =
+// row quarter w >> 1, column half w & 1) takes TWO 128-row slabs of A against one slab of B: 72 KB per 12.6 Mflop round, 0.75
+// of the bytes per flop, one workgroup per CU.  What a round waits for is memory LATENCY -- a fifth of the bytes miss the
+// XCD's L2 (an H slab is shared by the two row tiles an XCD walks, no more) and come from the Infinity Cache in 2 us or more,
+// while the round's MFMAs last 1.3 -- so the operands travel in three stages: memory -> registers TWO rounds ahead (two
+// register sets of nine 16-byte loads a lane, every load unconditional and clamped so that the compiler can count what is in
+// flight), registers -> the LDS image the round before last was read from, LDS -> MFMA; two images, ONE barrier per round, and
+// the waves drift apart inside a round so that one wave's operand reads fall under another's MFMAs.  (With the copy of round
+// r + 1 issued by global_load_lds at the start of round r -- one round ahead, all the two images allow -- a launch took 492 us
+// against 518 for the square tiles: a round lasted 3.7 us.)  Same slabs (k_split3's layout is untouched), same six products
+// per element in the same order, rounds in the same order: every accumulator is the 128 x 128 kernel's bit for bit.
+struct TileBf16TallSmem {
+    unsigned char a[2][3][2][8192];
+    unsigned char b[2][3][8192];
+};
+// a_slabs: the slab (row block 2 * tile_y, K-step 0) of plane 0; the second row block lies a_rb elements further.
+__device__ __forceinline__ void tile256_mac(Acc128 &acc, TileBf16TallSmem &sm, int k_begin, int k_end,
+                                            const unsigned short *__restrict__ a_slabs, size_t a_rb, size_t a_plane,
+                                            const unsigned short *__restrict__ b_slabs, size_t b_plane) {
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    if (k_begin >= k_end) return;
+    // this thread's share of a round: 16 bytes of each half of a quarter (2 KB) of one of the two A slabs and of an eighth
+    // (1 KB) of the B slab, per plane
+    const unsigned short *ga = a_slabs + (size_t)(wave >> 2) * a_rb + (size_t)(k_begin >> 5) * 4096 + (wave & 3) * 1024 + lane * 8;
+    const unsigned short *gb = b_slabs + (size_t)(k_begin >> 5) * 4096 + wave * 512 + lane * 8;
+    const int rounds = (k_end - k_begin) / KB16;
+    const int sw = ((lane & 31) >> 2) & 3;
+    const int r_off0 = (lane & 31) * 64 + (((lane >> 5) ^ sw) * 16), r_off1 = (lane & 31) * 64 + ((((lane >> 5) + 2) ^ sw) * 16);
+    auto fetch = [&](uint4v_t(&x)[9], int round) {
+        const size_t o = (size_t)min(round, rounds - 1) * 4096;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            x[3 * p + 0] = *reinterpret_cast<const uint4v_t *>(ga + o + p * a_plane);
+            x[3 * p + 1] = *reinterpret_cast<const uint4v_t *>(ga + o + p * a_plane + 512);
+            x[3 * p + 2] = *reinterpret_cast<const uint4v_t *>(gb + o + p * b_plane);
+        }
+    };
+    auto stash = [&](int buf, const uint4v_t(&x)[9]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            *reinterpret_cast<uint4v_t *>(sm.a[buf][p][wave >> 2] + (wave & 3) * 2048 + lane * 16) = x[3 * p + 0];
+            *reinterpret_cast<uint4v_t *>(sm.a[buf][p][wave >> 2] + (wave & 3) * 2048 + 1024 + lane * 16) = x[3 * p + 1];
+            *reinterpret_cast<uint4v_t *>(sm.b[buf][p] + wave * 1024 + lane * 16) = x[3 * p + 2];
+        }
+    };
+    auto mac = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t a[2][3], b[2][3];  // [i][plane]
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[i][p] = *reinterpret_cast<const bf16x8_t *>(sm.a[buf][p][wr >> 1] + ((wr & 1) * 64 + i * 32) * 64 + (s ? r_off1 : r_off0));
+                    b[i][p] = *reinterpret_cast<const bf16x8_t *>(sm.b[buf][p] + (wc * 64 + i * 32) * 64 + (s ? r_off1 : r_off0));
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float16_t c = acc.c[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+                    acc.c[i][j] = c;
+                }
+        }
+    };
+    uint4v_t xa[9], xb[9];
+    fetch(xb, 0);
+    fetch(xa, 1);
+    __syncthreads();  // whatever used this LDS before is done
+    stash(0, xb);
+    fetch(xb, 2);
+    // round r is multiplied out of image r & 1; meanwhile image (r + 1) & 1 takes round r + 1 from the register set that was
+    // loaded two rounds ago, and that set goes out again for round r + 3
+    for (int r = 0; r < rounds; r += 2) {
+        __syncthreads();  // image 0 holds round r; everybody is through with image 1 (round r - 1)
+        if (r + 1 < rounds) stash(1, xa);
+        fetch(xa, r + 3);
+        mac(0);
+        if (r + 1 < rounds) {
+            __syncthreads();
+            if (r + 2 < rounds) stash(0, xb);
+            fetch(xb, r + 4);
+            mac(1);
+        }
+    }
+}
+
 }  // namespace slk

@@ -349,6 +349,81 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
         partial[(size_t)(r0 + threadIdx.x) * p_stride + p_slot] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
 }
 
+// The same product on 256 x 128 tiles (mfma_bf16x3.h: tile256_mac): 512 threads, two 128-row slabs of D against one slab
+// of H per round.  Same column tiles, same rounds, same epilogue per 64 x 64 sub-tile: every partial sum is the 128 x 128
+// kernel's bit for bit (tests/test_gpu_parity.py::test_layer_error_bf16_path compares the two).  Taken for whole layers
+// (at least 2048 rows, a multiple of 256; no K chunks); everything else stays on the kernel above.
+constexpr int TALL = 256;
+__global__ __launch_bounds__(512) void k_error_tiles_bf16_tall(const float *__restrict__ W, const float *__restrict__ Q,
+                                                                  const unsigned short *__restrict__ Dp, const unsigned short *__restrict__ Hp,
+                                                                  int R, int n, float *__restrict__ partial, int n_tiles,
+                                                                  const int *__restrict__ sym_flag, int p_stride, int rpl, float *__restrict__ G,
+                                                                  int asym_mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TileBf16TallSmem &sm = *reinterpret_cast<TileBf16TallSmem *>(smem_raw);
+    __shared__ float rowpart[2][TALL];
+    // the tile order of k_error_tiles_bf16 with row tiles of 256: XCD x takes the row tiles [x rpx, (x + 1) rpx) and walks the
+    // column tiles up and down the depths in groups of 8
+    const int n_rt = R / TALL;
+    const int rpx = (n_rt + 7) / 8, per_xcd = rpx * n_tiles;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (slot >= per_xcd) return;
+    const int rank = slot / rpx;
+    const int tile_y = xcd * rpx + (slot - rank * rpx);
+    if (tile_y >= n_rt) return;
+    const int grp = rank >> 3, in_grp = rank & 7;
+    const int g_lo = grp * 8, g_hi = min(n_tiles, g_lo + 8) - 1;
+    const int tile_x = (grp & 1) ? g_hi - in_grp : g_lo + in_grp;
+    if (tile_x < g_lo || tile_x > g_hi) return;  // a last group shorter than 8
+    const int r0 = tile_y * TALL, j0 = tile_x * T32;
+    const int layer = r0 / rpl;
+    const bool full_k = G != nullptr || (sym_flag[layer] <= 0 && asym_mode != 2);
+    if (sym_flag[layer] <= 0 && !asym_mode) return;
+    Hp += (size_t)layer * 3 * n * n;
+    Acc128 acc;
+    acc.zero();
+    const int ksteps = n / 32;
+    const size_t d_plane = (size_t)(R / T32) * T32 * n, h_plane = (size_t)n * n, a_rb = (size_t)ksteps * 4096;
+    const unsigned short *a_slabs = Dp + (size_t)(2 * tile_y) * a_rb, *b_slabs = Hp + (size_t)tile_x * a_rb;
+    if (full_k) {
+        tile256_mac(acc, sm, 0, n, a_slabs, a_rb, d_plane, b_slabs, h_plane);
+    } else {
+        if (j0 > 0) {  // [0, j0) lies under the band: twice
+            tile256_mac(acc, sm, 0, j0, a_slabs, a_rb, d_plane, b_slabs, h_plane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc.c[i][j][r] = acc.c[i][j][r] * 2.0f;
+            __syncthreads();
+        }
+        tile256_mac(acc, sm, j0, j0 + T32, a_slabs, a_rb, d_plane, b_slabs, h_plane);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = j0 + wc * 64 + j * 32 + (lane & 31);
+                const size_t o = (size_t)(r0 + row) * n + col;
+                if (G) G[o] = acc.c[i][j][r];
+                s = s + acc.c[i][j][r] * (W[o] - Q[o]);
+            }
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
+            if ((lane & 31) == 0) rowpart[wc][row] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < TALL) partial[(size_t)(r0 + threadIdx.x) * p_stride + tile_x] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
+}
+
 // flag[0] = 1 iff H is bit-wise symmetric (flag must be preset to 1).  One workgroup per pair of mirrored
 // 64 x 64 tiles (a triangular list of pairs): tile (bi, bj) goes to LDS through coalesced 16-byte loads, tile
 // (bj, bi) is read the same way and compared with the transpose out of LDS -- every element is read once.
@@ -667,7 +742,15 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
         // flops as executed: six bfloat16 products per float32 product, over k <= j only (the definition of the
         // layer error, SURVEY.md 8d, counts 2 R n^2 float32 flops: a third of this, twice over)
         const int wgs = cb > 0 ? n_rt * n_slots : 8 * ((n_rt + 7) / 8) * ((n_tiles + 7) / 8 * 8);  // see the tile order in the kernel
-        if (dma)
+        // whole layers: 256 x 128 tiles (see k_error_tiles_bf16_tall; "no_tall_error" = 1 keeps the 128 x 128 kernel)
+        const bool tall = dma && cb == 0 && R % TALL == 0 && rpl % TALL == 0 && R / TALL >= 8 && !opt(OPT_NO_TALL_ERROR);
+        if (tall) {
+            SLK_LDS_OPT_IN(k_error_tiles_bf16_tall, sizeof(TileBf16TallSmem));
+            const int wgs_tall = 8 * ((R / TALL + 7) / 8) * ((n_tiles + 7) / 8 * 8);
+            SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, 2 * (R / TALL) * n_tiles, s,
+                      k_error_tiles_bf16_tall<<<wgs_tall, 512, sizeof(TileBf16TallSmem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym, n_slots,
+                                                                                              rpl, G, asym_mode));
+        } else if (dma)
             SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, cb > 0 ? wgs : n_rt * n_tiles, s,
                       k_error_tiles_bf16<true><<<wgs, 256, sizeof(TileBf16DmaSmem), s>>>(W, Q, Dp, Hp, R, n, partial, n_tiles, sym, n_slots,
                                                                                          cb, rpl, G, asym_mode));

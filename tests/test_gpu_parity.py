@@ -541,6 +541,45 @@ def test_integration_stub_runs(amd):
     assert np.array_equal(got.cpu().numpy(), amd.obq.quantize_opt(Ws, L["H"], cb))
 
 
+def test_layer_error_on_tall_tiles_is_the_square_tile_kernel(amd, slkopt):
+    """Whole layers (>= 2048 rows) take 256 x 128 tiles on the bfloat16 MFMA (k_error_tiles_bf16_tall: two images of a round in
+    LDS, half the workgroups); smaller ones and K-chunked shards stay on 128 x 128.  Same slabs, same six products per element,
+    same rounds: the row errors and the product G = (W - Q) H are the square-tile kernel's BIT FOR BIT -- symmetric H (half
+    the products), an H that is not symmetric (averaged planes), the full product for the local search, and a stack of layers."""
+    rng = np.random.default_rng(23)
+    R, n = 2304, 1024  # nine row tiles of 256: the XCD-aware order leaves a last partial group
+    W = torch.from_numpy(rng.standard_normal((R, n)).astype(np.float32)).cuda()
+    Q = W + 0.2 * torch.from_numpy(rng.standard_normal((R, n)).astype(np.float32)).cuda()
+    X = rng.standard_normal((2 * n, n)).astype(np.float32)
+    H = (X.T @ X / (2 * n)).astype(np.float32)
+    H = ((H + H.T) * np.float32(0.5)).astype(np.float32)
+    Ha = (H + np.float32(0.05) * np.triu(rng.standard_normal((n, n)).astype(np.float32), 1)).astype(np.float32)
+    Hs, Has = torch.from_numpy(H).cuda(), torch.from_numpy(Ha).cuda()
+
+    def both(fn):
+        tall = fn()
+        slkopt.setenv("SLK_NO_TALL_ERROR", "1")
+        square = fn()
+        slkopt.delenv("SLK_NO_TALL_ERROR")
+        return tall, square
+
+    for Hx in (Hs, Has):
+        tall, square = both(lambda: amd.engine.row_errors(W, Q, Hx))
+        assert torch.equal(tall, square)
+        (e1, G1), (e2, G2) = both(lambda: amd.engine.row_errors(W, Q, Hx, want_G=True))
+        assert torch.equal(e1, e2) and torch.equal(G1, G2)
+    D = (W - Q).double().cpu().numpy()
+    want = ((D @ H.astype(np.float64)) * D).sum(axis=1)
+    np.testing.assert_allclose(amd.engine.row_errors(W, Q, Hs).cpu().numpy(), want, rtol=1e-5)
+    # a stack of three layers of 768 rows (a multiple of 256) with Hessians of their own
+    H2 = torch.from_numpy(((H * np.float32(1.25)) + np.float32(0.01) * np.eye(n, dtype=np.float32))).cuda()
+    Wb, Qb = W.view(3, 768, n).contiguous(), Q.view(3, 768, n).contiguous()
+    tall, square = both(lambda: amd.engine.row_errors_batch(Wb, Qb, [Hs, H2, Has]))
+    assert torch.equal(tall, square)
+    one = amd.engine.row_errors(Wb[1].contiguous(), Qb[1].contiguous(), H2)
+    np.testing.assert_allclose(tall[1].cpu().numpy(), one.cpu().numpy(), rtol=2e-6)
+
+
 def test_layer_error_bf16_path(amd, slkopt):
     """The layer error of a symmetric Hessian runs on the bfloat16 MFMA with three pieces per operand
     (six products): every row within 1e-5 of the float64 value, like the float32 kernel it replaces --

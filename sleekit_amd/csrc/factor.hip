@@ -35,6 +35,7 @@ struct PanelSmem {
     double a21[PANEL][TP];  // this workgroup's tile of A21
     double lb[PANEL][TP];   // the previous panel's L of this workgroup's rows
     double rdiag[PANEL];    // 1 / L11[j][j]
+    int early_count;        // k_chol_chain: waves whose part of X's first three row blocks has left for memory
 };
 
 // 1/sqrt(d) to double precision: hardware estimate + two Newton steps (3 dependent ops each).
@@ -589,29 +590,36 @@ __device__ __forceinline__ void flag_publish(int *p, int value) {
 struct TileRegs {
     double2_t v[8];
 };
-template <int AUX>
+// (J0, J1: rows 8 J0 .. 8 J1 - 1 of the tile only)
+template <int AUX, int J0 = 0, int J1 = 8>
 __device__ __forceinline__ void tile_fetch(TileRegs &r, const GBuf &g, unsigned elem0, int ld) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r.v[j] = g.load2<AUX>(elem0 + (unsigned)(8 * j + (t >> 5)) * (unsigned)ld + 2u * (t & 31));
+    for (int j = J0; j < J1; ++j) r.v[j] = g.load2<AUX>(elem0 + (unsigned)(8 * j + (t >> 5)) * (unsigned)ld + 2u * (t & 31));
 }
+template <int J0 = 0, int J1 = 8>
 __device__ __forceinline__ void tile_stash(double (*img)[TP], const TileRegs &r) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<double2_t *>(&img[8 * j + (t >> 5)][2 * (t & 31)]) = r.v[j];
+    for (int j = J0; j < J1; ++j) *reinterpret_cast<double2_t *>(&img[8 * j + (t >> 5)][2 * (t & 31)]) = r.v[j];
 }
-template <int AUX>
+template <int AUX, int J0 = 0, int J1 = 8>
 __device__ __forceinline__ void tile_store_from_lds(const GBuf &g, unsigned elem0, int ld, const double (*img)[TP]) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = J0; j < J1; ++j)
         g.store2<AUX>(elem0 + (unsigned)(8 * j + (t >> 5)) * (unsigned)ld + 2u * (t & 31), *reinterpret_cast<const double2_t *>(&img[8 * j + (t >> 5)][2 * (t & 31)]));
 }
 
 // The diagonal tile in sm.t (blocks on and below the diagonal) -> L11 in sm.t, inv(L11) in sm.x (which must come in zeroed):
 // the strips, deferred block updates and inverse blocks of k_chol_panel for a workgroup without rows of its own, instruction
-// for instruction.  All 256 threads; returns (wave 0) the first column with a non-positive pivot, PANEL if none.
-__device__ __forceinline__ int diag_tile_factor(PanelSmem &sm, int lane, int wave) {
+// for instruction -- except for WHO runs the inverse's blocks and when: with no rows below to serve, wave 3 follows every diagonal
+// block's inverse with the off-diagonal blocks that have become possible (X[1][0] during strip 2; X[2][1], X[2][0] during strip
+// 3), and after the last pivot the inner sums of row 3 run beside the last diagonal block's inverse: one product and a barrier
+// stand between the last pivot and the end instead of two levels of the inverse.  Same blocks, same operations.
+// All 256 threads; returns (wave 0) the first column with a non-positive pivot, PANEL if none.
+template <class Early>
+__device__ __forceinline__ int diag_tile_factor(PanelSmem &sm, int lane, int wave, Early rows_0_and_1_are_in) {
     auto diag_inverse = [&](int kb) {
         const int c0 = 16 * kb, c = lane & 15;
         double xv[16];
@@ -632,14 +640,20 @@ __device__ __forceinline__ int diag_tile_factor(PanelSmem &sm, int lane, int wav
         double *c = &sm.t[16 * rb][16 * cb];
         blk_store_d(c, lane, blk_mma_abt(&sm.t[16 * rb][16 * kb], &sm.t[16 * cb][16 * kb], blk_load_d(c, lane), -1.0, lane));
     };
-    auto x_block = [&](int rb, int cb) {
+    auto x_inner = [&](int rb, int cb) {  // sum_{k = cb .. rb-1} L[rb][k] X[k][cb]
         double4_t sacc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k >= cb && k < rb) sacc = blk_mma_ab(&sm.t[16 * rb][16 * k], &sm.x[16 * k][16 * cb], sacc, lane);
+        return sacc;
+    };
+    auto x_finish = [&](int rb, int cb, double4_t sacc) {  // X[rb][cb] = -X[rb][rb] * that
         const double4_t z = {0.0, 0.0, 0.0, 0.0};
         blk_store_d(&sm.x[16 * rb][16 * cb], lane, blk_mma_a_reg(&sm.x[16 * rb][16 * rb], sacc, z, -1.0, lane));
     };
+    auto x_block = [&](int rb, int cb) { x_finish(rb, cb, x_inner(rb, cb)); };
+    // (a wave that reads back LDS words it has just written: its LDS operations complete in order)
+    auto own_writes = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     int first_bad = PANEL;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -670,13 +684,22 @@ __device__ __forceinline__ int diag_tile_factor(PanelSmem &sm, int lane, int wav
         } else if (kb == 0) {
         } else if (wave == 3) {
             diag_inverse(kb - 1);
+            own_writes();
+            if (kb == 2) x_block(1, 0);  // X[0][0] came with strip 1, X[1][1] just now
+            if (kb == 3) {
+                x_block(2, 1);
+                x_block(2, 0);  // wants X[1][0] (strip 2's side work) and X[0][0]
+            }
         } else {
 #pragma unroll
             for (int rb = kb + 1; rb < 4; ++rb)
 #pragma unroll
                 for (int cb = kb + 1; cb <= rb; ++cb)
                     if (block_owner(rb, cb) == wave) block_update(rb, cb, kb - 1);
-            if (kb == 3 && wave == 1) x_block(1, 0);
+            // rows 0 and 1 of X are complete when strip 3 starts (X[1][0] came with strip 2's side work): they go out NOW, by
+            // the two waves that have nothing else left to do, so that the next workgroup of the chain multiplies by them
+            // while the last strip's pivots run here
+            if (kb == 3) rows_0_and_1_are_in(wave - 1);
         }
         __syncthreads();
         if (kb < 3) {
@@ -686,19 +709,19 @@ __device__ __forceinline__ int diag_tile_factor(PanelSmem &sm, int lane, int wav
             __syncthreads();
         }
     }
+    double4_t row3 = {0.0, 0.0, 0.0, 0.0};
     if (wave == 3) diag_inverse(3);
-    else if (wave == 0) x_block(2, 0);
-    else if (wave == 1) x_block(2, 1);
+    else row3 = x_inner(3, wave);  // rows 0 .. 2 of X are complete
     __syncthreads();
-    if (wave < 3) x_block(3, wave);
+    if (wave < 3) x_finish(3, wave, row3);
     __syncthreads();
     return first_bad;
 }
 
-// flags of one matrix: [0, nt) xready[p] = 1 when inv(L_pp) of panel p is in X; [nt, 2 nt) rowdone[p] = how many L tiles of
+// flags of one matrix: [0, nt) xready[p] = 1 when row blocks 0 and 1 of inv(L_pp) of panel p are in X, 2 when all of it is; [nt, 2 nt) rowdone[p] = how many L tiles of
 // tile row p (inside its outer block) are in A.  Zeroed by k_clear_info before the factorisation starts.
 __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, int ld, int K0, int nb, double *__restrict__ Xall,
-                                                    int *__restrict__ info, int *__restrict__ flags_all) {
+                                                    int *__restrict__ info, int *__restrict__ flags_all, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PanelSmem &sm = *reinterpret_cast<PanelSmem *>(smem_raw);
     // roles of the four images while this workgroup walks its row:  t: L(q', s) operand   x: X_q
@@ -713,6 +736,18 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
     const int row0 = K0 + PANEL * r;
     auto elem = [&](int tr, int tc) { return (unsigned)(K0 + PANEL * tr) * (unsigned)ld + (unsigned)(K0 + PANEL * tc); };  // tile (tr, tc) of the block
     bool alive = true;  // false once a wait gave up: the workgroup goes on without waiting (finite, results void, status says so)
+    if (t == 0) sm.early_count = 0;  // (read after many barriers)
+    // (measurement, SLK_WIN_DBG=8: where wave 0 of the workgroups r >= 1 spends the cycles between seeing X_{r-1} and
+    // publishing X_r -- the chain's critical path; g_panel_cycles, read by slk_probe_panel_cycles / tools/micro_panel.py)
+    const bool timing = dbg && r > 0 && blockIdx.z == 0 && wave == 0;
+    long long tmark = 0;
+    auto lap = [&](int slot) {
+        if (timing) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (lane == 0 && slot >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(&g_panel_cycles[slot]), (unsigned long long)(now - tmark));
+            tmark = now;
+        }
+    };
 
     // T_r, blocks on and below the diagonal, in registers (D layout): the i-th such block belongs to wave i & 3 (block_syrk's split)
     double4_t tp[3];
@@ -776,28 +811,55 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
                     update_cn(cn);
                 }
             }
-            // (2) X_q crosses: L(r, q) = C_q inv(L_qq)^T
+            // (2) X_q crosses in two parts -- its row blocks 0 and 1 while workgroup q is still in its last strip's pivots, then
+            //     row blocks 2 and 3: L(r, q) = C_q inv(L_qq)^T column block by column block (block cb wants X's row block cb
+            //     only), and of T_r's update by it, sum_kq L[rb][kq] L[cb][kq]^T, the terms kq = 0, 1 -- same chain of additions,
+            //     kq ascending -- before the second part has arrived
+            const bool last = q + 1 == r;
+            auto l_block = [&](int cb) {
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k <= cb) acc = blk_mma_abt(&sm.a21[16 * wave][16 * k], &sm.x[16 * cb][16 * k], acc, 1.0, lane);
+                blk_store_d(&sm.lb[16 * wave][16 * cb], lane, acc);
+            };
+            double4_t tacc[3];
+            auto t_terms = [&](int kq0, int kq1) {
+                int i = 0;
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb <= rb; ++cb, ++i)
+                        if ((i & 3) == wave) {
+                            double4_t acc = kq0 == 0 ? (double4_t){0.0, 0.0, 0.0, 0.0} : tacc[i >> 2];
+#pragma unroll
+                            for (int kq = 0; kq < 4; ++kq)
+                                if (kq >= kq0 && kq < kq1) acc = blk_mma_abt(&sm.lb[16 * rb][16 * kq], &sm.lb[16 * cb][16 * kq], acc, 1.0, lane);
+                            tacc[i >> 2] = acc;
+                        }
+            };
             if (alive) alive = flag_wait(&xready[p0 + q], 1);
-            tile_fetch<AUX_SC1>(ra, gx, elem(q, q), ld);
+            tile_fetch<AUX_SC1, 0, 4>(ra, gx, elem(q, q), ld);
             __syncthreads();
-            tile_stash(sm.x, ra);
+            tile_stash<0, 4>(sm.x, ra);
             __syncthreads();
-            {
-                double4_t lq[4];
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k <= cb) acc = blk_mma_abt(&sm.a21[16 * wave][16 * k], &sm.x[16 * cb][16 * k], acc, 1.0, lane);
-                    lq[cb] = acc;
-                }
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) blk_store_d(&sm.lb[16 * wave][16 * cb], lane, lq[cb]);
-            }
+            l_block(0);
+            l_block(1);
             __syncthreads();
-            // L(r, q) to memory (write-through); T_r -= L(r, q) L(r, q)^T meanwhile
+            t_terms(0, 2);
+            if (alive) alive = flag_wait(&xready[p0 + q], 2);
+            if (last) lap(-1);  // the clock of the critical path starts when the LAST part of X_{r-1} is seen
+            tile_fetch<AUX_SC1, 4, 8>(ra, gx, elem(q, q), ld);
+            tile_stash<4, 8>(sm.x, ra);  // (rows 32 .. 63 of the image: nobody has read them since the barriers above)
+            __syncthreads();
+            if (last) lap(0);  // row blocks 2 and 3 of X_{r-1} in LDS
+            l_block(2);
+            l_block(3);
+            __syncthreads();
+            if (last) lap(1);  // the last two column blocks of L(r, r-1)
+            // L(r, q) to memory (write-through); the last terms of T_r's update meanwhile
             tile_store_from_lds<AUX_SC1>(ga, elem(r, q), ld, sm.lb);
+            t_terms(2, 4);
             {
                 int i = 0;
 #pragma unroll
@@ -805,11 +867,11 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
 #pragma unroll
                     for (int cb = 0; cb <= rb; ++cb, ++i)
                         if ((i & 3) == wave) {
-                            double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                            for (int kq = 0; kq < 4; ++kq) acc = blk_mma_abt(&sm.lb[16 * rb][16 * kq], &sm.lb[16 * cb][16 * kq], acc, 1.0, lane);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) tp[i >> 2][j] = tp[i >> 2][j] - acc[j];
+                            for (int j = 0; j < 4; ++j) tp[i >> 2][j] = tp[i >> 2][j] - tacc[i >> 2][j];
+                            // the last panel's update completes T_r: straight into its image (t has served as an operand for
+                            // the last time: nothing reads it in this iteration)
+                            if (last) blk_store_d(&sm.t[16 * rb][16 * cb], lane, tp[i >> 2]);
                         }
             }
             if (more) {
@@ -823,13 +885,15 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) blk_store_d(&sm.a21[16 * wave][16 * cb], lane, cn[cb]);
             } else {
+                lap(2);  // the update of T_r
                 flag_publish(&rowdone[p0 + r], q + 1);
+                lap(3);  // L(r, r-1) drained, row flag
             }
         }
-        __syncthreads();  // lb's readers (the last T update) are through before the images change roles
-    }
-    // ---- the turn: T_r -> sm.t, factor, invert, publish
-    {
+        // (flag_publish's barrier stands between the stores of T_r above and its readers below; x holds X_{r-1}, whose blocks
+        // above the diagonal are exactly zero -- what the inverse below wants there -- and whose other blocks it overwrites)
+    } else {
+        // ---- workgroup 0: T_0 -> its image, x cleared
         int i = 0;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
@@ -837,9 +901,29 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
             for (int cb = 0; cb <= rb; ++cb, ++i)
                 if ((i & 3) == wave) blk_store_d(&sm.t[16 * rb][16 * cb], lane, tp[i >> 2]);
         for (int e = t; e < PANEL * PANEL; e += 256) sm.x[e >> 6][e & 63] = 0.0;
+        __syncthreads();
     }
-    __syncthreads();
-    const int first_bad = diag_tile_factor(sm, lane, wave);
+    // ---- the turn: factor, invert, publish
+    lap(4);  // T_r into its image
+    // (the early publication: waves 1 and 2 store a row block of X each during the last strip; each drains its own stores, and the
+    // one that is second to say so in LDS sets the flag to 1 -- Guideline 16's form with a counter in LDS instead of a workgroup
+    // barrier, which the wave in the pivot chain must not be held up by)
+    const int first_bad = diag_tile_factor(sm, lane, wave, [&](int rowblock) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = 16 * rowblock + 2 * j + (lane >> 5);
+            gx.store2<AUX_SC1>(elem(r, r) + (unsigned)row * (unsigned)ld + 2u * (lane & 31), *reinterpret_cast<const double2_t *>(&sm.x[row][2 * (lane & 31)]));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(&sm.early_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived == 1) {
+            if (lane == 0) __hip_atomic_store(&xready[p0 + r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this word is stored again, = 2, behind later barriers: in that order)
+        }
+    });
+    lap(5);  // strips, inverse
     if (t == 0) {
         int expect = 0;
         if (!alive) {
@@ -849,8 +933,10 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
             __hip_atomic_compare_exchange_strong(info, &expect, row0 + first_bad + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    tile_store_from_lds<AUX_SC1>(gx, elem(r, r), ld, sm.x);  // exactly zero above the diagonal
-    flag_publish(&xready[p0 + r], 1);
+    tile_store_from_lds<AUX_SC1, 4, 8>(gx, elem(r, r), ld, sm.x);  // row blocks 2 and 3 (the tile is exactly zero above the diagonal)
+    flag_publish(&xready[p0 + r], 2);
+    lap(6);  // X_r's last row block stored, drained, published
+    if (timing && lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&g_panel_cycles[15]), 1ull);
 }
 
 // The rows below an outer block's diagonal block, after k_chol_chain: for every 16-row strip, panel by panel (left-looking,
@@ -1093,7 +1179,7 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
             const int nb = (K1 - K0) / PANEL, below_tiles = (ld - K1) / PANEL;
             const double e = 64.0 * nb;
             SLK_RUN_W("chol_chain", Bd * e * e * e / 3.0, Bd * 12.0 * e * e, nb * batch, s,
-                      k_chol_chain<<<dim3(nb, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, K0, nb, X, info, flags));
+                      k_chol_chain<<<dim3(nb, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, K0, nb, X, info, flags, opt(OPT_WIN_DBG) & 8));
             if (below_tiles > 0)
                 SLK_RUN_W("chol_rows_below", Bd * 64.0 * below_tiles * e * e, Bd * (16.0 * 64 * below_tiles * e + 4.0 * e * e), 4 * below_tiles * batch, s,
                           k_chol_rows_below<<<dim3(4 * below_tiles, 1, B), 256, sizeof(RowsBelowSmem), s>>>(A, ld, K0, nb, X));

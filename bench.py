@@ -222,14 +222,14 @@ class Leg:
         self.host_seconds = 0.0  # spent in quantize_stream (reset by timed())
 
     # -- the step
-    def strip_mean(self, lay, check=True):
+    def strip_mean(self, lay, check=True, out=None):
         """a2, remove_input_bias (obq.py:14-25): part of cfg3's path, so inside the step.  The derived layer vouches for the
         symmetry of the STRIPPED Hessian only as far as it was verified on it at setup."""
         from sleekit_amd import _device as dev
         from sleekit_amd import _lib
 
         n = lay["H"].shape[0]
-        out = torch.empty_like(lay["H"])
+        out = torch.empty_like(lay["H"]) if out is None else out
         _lib.check(_lib.lib.slk_hessian_strip_mean(dev.ptr(lay["H"]), dev.ptr(lay["mean"]), n, dev.ptr(out), dev.stream_handle()))
         return dict(lay, H=out, symmetric=bool(lay.get("stripped_symmetric", False)) if check else False)
 
@@ -238,7 +238,16 @@ class Leg:
 
         todo = self.layers if stream_layers is None else stream_layers
         if self.strip:
-            todo = [self.strip_mean(lay) for lay in todo]
+            # the stripped Hessians of a step live in one of depth + 2 fixed sets of buffers, taken in turn (a step's set is
+            # free again when the step depth + 1 before it has been waited for, below): the same bytes every time round, so
+            # that the timed steps ask the allocator for nothing -- tensors made per step and dropped while side streams still
+            # hold them (record_stream) come back to the pool at times that depend on the run
+            ring = self.__dict__.setdefault("_strip_ring", [None] * (self.depth + 2))
+            slot = self.__dict__.get("_strip_turn", 0) % len(ring)
+            self._strip_turn = slot + 1
+            if ring[slot] is None or len(ring[slot]) != len(todo) or any(b.shape != lay["H"].shape for b, lay in zip(ring[slot], todo)):
+                ring[slot] = [torch.empty_like(lay["H"]) for lay in todo]
+            todo = [self.strip_mean(lay, out=buf) for lay, buf in zip(todo, ring[slot])]
         # join=False: consecutive steps are independent batches, so the next step's factorisations start under
         # this step's loops (the fence waits for everything before the clock stops); the factorisation statuses of every
         # layer are registered and checked after the timed region (raise_pending)
@@ -306,14 +315,14 @@ class Leg:
             env.fence()
             el = time.perf_counter() - t0
             # (a hipMalloc inside the timed region costs tens of ms: a region that saw one is measured again -- the pools have
-            # grown by what it needed -- at most twice; the count of the region that is REPORTED goes into the line)
+            # grown by what it needed -- at most four times; the count of the region that is REPORTED goes into the line)
             grew = device_mallocs() - mallocs
             if env.world > 1:
                 t = torch.tensor([el, float(grew)], dtype=torch.float64, device=env.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el, grew = float(t[0].item()), int(t[1].item())
             self.device_mallocs_while_timed = grew
-            if grew == 0 or self.repeats >= 2:
+            if grew == 0 or self.repeats >= 4:
                 break
             self.repeats += 1
         return el, out
@@ -566,6 +575,7 @@ class Leg:
 
         torch.cuda.synchronize()
         self.layers, self.made, self.backend, self.in_flight = [], {}, None, []
+        self.__dict__.pop("_strip_ring", None)
         dev.release_workspaces()
         torch.cuda.empty_cache()
 

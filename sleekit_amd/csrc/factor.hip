@@ -1180,6 +1180,12 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
             const double e = 64.0 * nb;
             SLK_RUN_W("chol_chain", Bd * e * e * e / 3.0, Bd * 12.0 * e * e, nb * batch, s,
                       k_chol_chain<<<dim3(nb, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, K0, nb, X, info, flags, opt(OPT_WIN_DBG) & 8));
+            if (below_tiles > 0 && forked >= 0) {
+                // look-ahead: the rows below read tiles that the REST of the previous block's outer update (helper stream)
+                // writes; the chain above did not -- it ran beside it
+                SLK_HIP(hipStreamWaitEvent(s, helper.events[2 * forked + 1], 0));
+                forked = -1;
+            }
             if (below_tiles > 0)
                 SLK_RUN_W("chol_rows_below", Bd * 64.0 * below_tiles * e * e, Bd * (16.0 * 64 * below_tiles * e + 4.0 * e * e), 4 * below_tiles * batch, s,
                           k_chol_rows_below<<<dim3(4 * below_tiles, 1, B), 256, sizeof(RowsBelowSmem), s>>>(A, ld, K0, nb, X));
@@ -1226,7 +1232,30 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
             const int m = nt - t0, total = m * (m + 1) / 2;
             const double tiles = total;
             const int ahead = OUTER / TILE;  // tile columns of the next outer block
-            if (lookahead && m >= LOOKAHEAD_MIN_TILES) {
+            if (lookahead && chain && m >= LOOKAHEAD_MIN_TILES) {
+                // LOOK-AHEAD with the chain (round 4).  The next block's chain reads its DIAGONAL block and nothing else; the
+                // rows below it are not read before that chain is through (k_chol_rows_below).  So only the diagonal block's
+                // tiles (<= 36) are updated here, on the caller's stream, and the next chain starts at once; all the rest of
+                // the outer update -- the rectangle under that block and the triangle beyond -- goes to the helper stream and
+                // runs beside the chain (8 CUs for ~130 us), joined before the next block's rows below are made (above).
+                // Same tiles, same K ranges, one update per tile and block in the order of the blocks (events): same bits.
+                SLK_HIP(hipEventRecord(helper.events[2 * block], s));  // this block's chain and rows below are done
+                const int nbn = ahead < m ? ahead : m, td = nbn * (nbn + 1) / 2;
+                SLK_RUN_W("chol_syrk_ahead", Bd * td * 2.0 * 64 * 64 * (K1 - K0), Bd * (16.0 * nbn * 64 * (K1 - K0) + td * 16.0 * 64 * 64), td * batch, s,
+                          k_syrk_tiles<<<dim3(nbn, nbn, B), 256, 0, s>>>(A, ld, t0, t0, K0, K1));
+                SLK_HIP(hipStreamWaitEvent(helper.stream, helper.events[2 * block], 0));
+                const int m2 = m - nbn, total2 = m2 * (m2 + 1) / 2;
+                if (m2 > 0) {
+                    SLK_RUN_W("chol_syrk_outer", Bd * (double)nbn * m2 * 2.0 * 64 * 64 * (K1 - K0), Bd * (8.0 * (ld - K1) * (K1 - K0) + (double)nbn * m2 * 16.0 * 64 * 64),
+                              (double)nbn * m2 * batch, helper.stream,
+                              k_syrk_tiles<<<dim3(nbn, m2, B), 256, 0, helper.stream>>>(A, ld, t0 + nbn, t0, K0, K1));
+                    SLK_RUN_W("chol_syrk_outer", Bd * total2 * 2.0 * 64 * 64 * (K1 - K0), Bd * (8.0 * (ld - K1) * (K1 - K0) + total2 * 16.0 * 64 * 64),
+                              (double)total2 * batch, helper.stream,
+                              k_syrk_triangle<<<dim3(8 * ((total2 + 7) / 8), 1, B), 256, 0, helper.stream>>>(A, ld, t0 + nbn, m2, K0, K1));
+                }
+                SLK_HIP(hipEventRecord(helper.events[2 * block + 1], helper.stream));
+                forked = block;
+            } else if (lookahead && m >= LOOKAHEAD_MIN_TILES) {
                 // LOOK-AHEAD.  Only the next outer block's columns are needed before its panels can start: those
                 // (4 m - 6 tiles) are updated here, on the caller's stream; the rest of the triangle goes to the helper
                 // stream and runs beside the next block's panels (<= 64 workgroups each), which it used to hold up.

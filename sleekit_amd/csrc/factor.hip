@@ -720,6 +720,12 @@ __device__ __forceinline__ int diag_tile_factor(PanelSmem &sm, int lane, int wav
 
 // flags of one matrix: [0, nt) xready[p] = 1 when row blocks 0 and 1 of inv(L_pp) of panel p are in X, 2 when all of it is; [nt, 2 nt) rowdone[p] = how many L tiles of
 // tile row p (inside its outer block) are in A.  Zeroed by k_clear_info before the factorisation starts.
+// BELOW = true: the same walk for the tile rows BELOW the diagonal block, launched after the chain (every X_q and every L of
+// the block are in memory: nothing to wait for, nothing to publish, no diagonal tile): workgroup x owns tile row nb + x and
+// makes L(r, q) for all nb panels.  The wide form of k_chol_rows_below -- 64 rows per workgroup instead of 16: a quarter of
+// the workgroups, each step 64 MFMAs a wave for two staged operands instead of 16 for one -- for factorisations that share
+// the chip with other layers' kernels (what it costs the chip counts there, not how long a launch lasts).
+template <bool BELOW>
 __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, int ld, int K0, int nb, double *__restrict__ Xall,
                                                     int *__restrict__ info, int *__restrict__ flags_all, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -727,7 +733,8 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
     // roles of the four images while this workgroup walks its row:  t: L(q', s) operand   x: X_q
     //                                                                a21: C_q (complete, waits for X_q)   lb: L(r, s) operand, L(r, q)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int r = blockIdx.x, nt = ld / PANEL, p0 = K0 / PANEL;
+    const int r = BELOW ? nb + (int)blockIdx.x : (int)blockIdx.x, nt = ld / PANEL, p0 = K0 / PANEL;
+    const int rq = BELOW ? nb : r;  // panels this row walks
     const size_t mat = (size_t)ld * ld;
     double *A = Aall + (size_t)blockIdx.z * mat;
     const GBuf ga(A, mat * sizeof(double)), gx(Xall + (size_t)blockIdx.z * mat, mat * sizeof(double));
@@ -739,7 +746,7 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
     if (t == 0) sm.early_count = 0;  // (read after many barriers)
     // (measurement, SLK_WIN_DBG=8: where wave 0 of the workgroups r >= 1 spends the cycles between seeing X_{r-1} and
     // publishing X_r -- the chain's critical path; g_panel_cycles, read by slk_probe_panel_cycles / tools/micro_panel.py)
-    const bool timing = dbg && r > 0 && blockIdx.z == 0 && wave == 0;
+    const bool timing = !BELOW && dbg && r > 0 && blockIdx.z == 0 && wave == 0;
     long long tmark = 0;
     auto lap = [&](int slot) {
         if (timing) {
@@ -751,7 +758,7 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
 
     // T_r, blocks on and below the diagonal, in registers (D layout): the i-th such block belongs to wave i & 3 (block_syrk's split)
     double4_t tp[3];
-    {
+    if constexpr (!BELOW) {
         int i = 0;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
@@ -778,14 +785,23 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
         }
     };
 
-    if (r > 0) {
+    // L(r, 0 .. count-1) are in memory: this workgroup's own later loads may see them; the other rows of the chain are told
+    auto row_done = [&](int count) {
+        if constexpr (BELOW) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            flag_publish(&rowdone[p0 + r], count);
+        }
+    };
+    if (rq > 0) {
         TileRegs ra, rb_;
         double4_t cn[4];  // C_{q+1} in the making: this wave's row block
         // C_0 = A(r, 0) as it stands
         tile_fetch<0>(ra, ga, elem(r, 0), ld);
         tile_stash(sm.a21, ra);
-        for (int q = 0; q < r; ++q) {
-            const bool more = q + 1 < r;
+        for (int q = 0; q < rq; ++q) {
+            const bool more = q + 1 < rq;
             // (1) while workgroup q is in its pivot chain: the updates s < q of the NEXT tile, C_{q+1} = A(r, q+1) - ...
             if (more) {
 #pragma unroll
@@ -794,7 +810,7 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
                     for (int j = 0; j < 4; ++j)
                         cn[cb][j] = A[(size_t)(row0 + 16 * wave + (lane >> 4) + 4 * j) * ld + K0 + PANEL * (q + 1) + 16 * cb + (lane & 15)];
                 if (q > 0) {
-                    alive = alive && flag_wait(&rowdone[p0 + q + 1], 1);
+                    if (!BELOW) alive = alive && flag_wait(&rowdone[p0 + q + 1], 1);
                     tile_fetch<AUX_SC1>(ra, ga, elem(r, 0), ld);
                     tile_fetch<AUX_SC1>(rb_, ga, elem(q + 1, 0), ld);
                 }
@@ -804,7 +820,7 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
                     tile_stash(sm.t, rb_);
                     __syncthreads();
                     if (s + 1 < q) {  // the next pair is in flight during the products
-                        if (alive) alive = flag_wait(&rowdone[p0 + q + 1], s + 2);
+                        if (!BELOW && alive) alive = flag_wait(&rowdone[p0 + q + 1], s + 2);
                         tile_fetch<AUX_SC1>(ra, ga, elem(r, s + 1), ld);
                         tile_fetch<AUX_SC1>(rb_, ga, elem(q + 1, s + 1), ld);
                     }
@@ -815,7 +831,7 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
             //     row blocks 2 and 3: L(r, q) = C_q inv(L_qq)^T column block by column block (block cb wants X's row block cb
             //     only), and of T_r's update by it, sum_kq L[rb][kq] L[cb][kq]^T, the terms kq = 0, 1 -- same chain of additions,
             //     kq ascending -- before the second part has arrived
-            const bool last = q + 1 == r;
+            const bool last = !BELOW && q + 1 == r;
             auto l_block = [&](int cb) {
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -838,7 +854,7 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
                             tacc[i >> 2] = acc;
                         }
             };
-            if (alive) alive = flag_wait(&xready[p0 + q], 1);
+            if (!BELOW && alive) alive = flag_wait(&xready[p0 + q], 1);
             tile_fetch<AUX_SC1, 0, 4>(ra, gx, elem(q, q), ld);
             __syncthreads();
             tile_stash<0, 4>(sm.x, ra);
@@ -846,8 +862,8 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
             l_block(0);
             l_block(1);
             __syncthreads();
-            t_terms(0, 2);
-            if (alive) alive = flag_wait(&xready[p0 + q], 2);
+            if (!BELOW) t_terms(0, 2);
+            if (!BELOW && alive) alive = flag_wait(&xready[p0 + q], 2);
             if (last) lap(-1);  // the clock of the critical path starts when the LAST part of X_{r-1} is seen
             tile_fetch<AUX_SC1, 4, 8>(ra, gx, elem(q, q), ld);
             tile_stash<4, 8>(sm.x, ra);  // (rows 32 .. 63 of the image: nobody has read them since the barriers above)
@@ -859,8 +875,8 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
             if (last) lap(1);  // the last two column blocks of L(r, r-1)
             // L(r, q) to memory (write-through); the last terms of T_r's update meanwhile
             tile_store_from_lds<AUX_SC1>(ga, elem(r, q), ld, sm.lb);
-            t_terms(2, 4);
-            {
+            if constexpr (!BELOW) {
+                t_terms(2, 4);
                 int i = 0;
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb)
@@ -876,23 +892,23 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
             }
             if (more) {
                 // (3) the last update of C_{q+1}: panel q's, with the L(r, q) just made (in lb) and L(q+1, q) from its owner
-                if (alive) alive = flag_wait(&rowdone[p0 + q + 1], q + 1);
+                if (!BELOW && alive) alive = flag_wait(&rowdone[p0 + q + 1], q + 1);
                 tile_fetch<AUX_SC1>(rb_, ga, elem(q + 1, q), ld);
                 tile_stash(sm.t, rb_);  // (t's readers finished before the barriers of (2))
-                flag_publish(&rowdone[p0 + r], q + 1);  // (its barrier also closes the stash)
+                row_done(q + 1);  // (its barrier also closes the stash)
                 update_cn(cn);
                 // C_{q+1} is complete: into a21, each wave its own row block (the only one it reads back)
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) blk_store_d(&sm.a21[16 * wave][16 * cb], lane, cn[cb]);
             } else {
                 lap(2);  // the update of T_r
-                flag_publish(&rowdone[p0 + r], q + 1);
+                row_done(q + 1);
                 lap(3);  // L(r, r-1) drained, row flag
             }
         }
         // (flag_publish's barrier stands between the stores of T_r above and its readers below; x holds X_{r-1}, whose blocks
         // above the diagonal are exactly zero -- what the inverse below wants there -- and whose other blocks it overwrites)
-    } else {
+    } else if (!BELOW) {
         // ---- workgroup 0: T_0 -> its image, x cleared
         int i = 0;
 #pragma unroll
@@ -903,6 +919,7 @@ __global__ __launch_bounds__(256) void k_chol_chain(double *__restrict__ Aall, i
         for (int e = t; e < PANEL * PANEL; e += 256) sm.x[e >> 6][e & 63] = 0.0;
         __syncthreads();
     }
+    if constexpr (BELOW) return;
     // ---- the turn: factor, invert, publish
     lap(4);  // T_r into its image
     // (the early publication: waves 1 and 2 store a row block of X each during the last strip; each drains its own stores, and the
@@ -1169,7 +1186,8 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
     const bool split = !chain && !want_lookahead && sp != 2 && (sp == 1 || batch > 1 || n >= 8192);
     if (split) SLK_LDS_OPT_IN(k_panel_below, sizeof(BelowSmem));
     if (chain) {
-        SLK_LDS_OPT_IN(k_chol_chain, sizeof(PanelSmem));
+        SLK_LDS_OPT_IN(k_chol_chain<false>, sizeof(PanelSmem));
+        SLK_LDS_OPT_IN(k_chol_chain<true>, sizeof(PanelSmem));
         SLK_LDS_OPT_IN(k_chol_rows_below, sizeof(RowsBelowSmem));
     }
     int block = 0, forked = -1;  // forked: the last block whose rest went to the helper and has not been joined
@@ -1179,14 +1197,23 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
             const int nb = (K1 - K0) / PANEL, below_tiles = (ld - K1) / PANEL;
             const double e = 64.0 * nb;
             SLK_RUN_W("chol_chain", Bd * e * e * e / 3.0, Bd * 12.0 * e * e, nb * batch, s,
-                      k_chol_chain<<<dim3(nb, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, K0, nb, X, info, flags, opt(OPT_WIN_DBG) & 8));
+                      k_chol_chain<false><<<dim3(nb, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, K0, nb, X, info, flags, opt(OPT_WIN_DBG) & 8));
             if (below_tiles > 0 && forked >= 0) {
                 // look-ahead: the rows below read tiles that the REST of the previous block's outer update (helper stream)
                 // writes; the chain above did not -- it ran beside it
                 SLK_HIP(hipStreamWaitEvent(s, helper.events[2 * forked + 1], 0));
                 forked = -1;
             }
-            if (below_tiles > 0)
+            // the rows below: 16 rows per workgroup (k_chol_rows_below: 45 us a launch at 4096 columns, most of the chip) or,
+            // "rows_below_wide" = 1, 64 rows per workgroup (k_chol_chain<true>: 103 us, a quarter of the workgroups: 0.6 of the
+            // chip time).  Measured on whole streams, wide against narrow: headline 5257 / 5272 Mweights/s, one rank of 8
+            // 3.66 / 3.61 ms per step, BLOOM-560M 5139 / 5084 -- nothing in it, and a single factorisation is 0.4 ms longer:
+            // narrow stays.
+            const bool wide = opt(OPT_ROWS_BELOW_WIDE) == 1;
+            if (below_tiles > 0 && wide)
+                SLK_RUN_W("chol_rows_below", Bd * 64.0 * below_tiles * e * e, Bd * (16.0 * 64 * below_tiles * e + 4.0 * e * e), below_tiles * batch, s,
+                          k_chol_chain<true><<<dim3(below_tiles, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, K0, nb, X, info, flags, 0));
+            else if (below_tiles > 0)
                 SLK_RUN_W("chol_rows_below", Bd * 64.0 * below_tiles * e * e, Bd * (16.0 * 64 * below_tiles * e + 4.0 * e * e), 4 * below_tiles * batch, s,
                           k_chol_rows_below<<<dim3(4 * below_tiles, 1, B), 256, sizeof(RowsBelowSmem), s>>>(A, ld, K0, nb, X));
         }

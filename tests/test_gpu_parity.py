@@ -294,6 +294,13 @@ def test_factor_panel_step_in_two_launches_is_the_one_launch_form(amd, n):
     assert int(two[3][2].item()) != 0
     for b in range(3):
         assert torch.equal(two_b[1][b], two[b][1])
+    # the rows below a diagonal block: 64 rows per workgroup (k_chol_chain<true>, the default beside other layers' kernels)
+    # and 16 (k_chol_rows_below, the default of a factorisation that looks ahead) -- forced either way, same U
+    for wide in (1, 2):
+        with amd.lib.option("rows_below_wide", wide):
+            o, U, i = amd.engine.factorize(Hs[2], n, 0.01, amd.lib.ORDER_DIAG)
+            ob, Ub, ib = amd.engine.factorize_batch(Hs, n, 0.01, amd.lib.ORDER_DIAG)
+        assert torch.equal(U, two[2][1]) and int(i.item()) == 0 and torch.equal(Ub, two_b[1]), wide
 
 
 def test_factor_of_plain_matrix_and_not_pd(amd):

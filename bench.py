@@ -82,7 +82,8 @@ import torch.distributed as dist
 PEAK = {"hbm": (8.0e12, "GB/s"), "mfma_f64": (78.6e12, "TFLOP/s"), "mfma_f32": (157.3e12, "TFLOP/s"), "mfma_bf16": (2.5e15, "TFLOP/s")}
 KERNEL_DTYPE = {
     "chol_panel": "mfma_f64", "chol_syrk_inner": "mfma_f64", "chol_syrk_outer": "mfma_f64", "trtri_stage0": "mfma_f64", "trtri_stage1": "mfma_f64",
-    "chol_syrk_ahead": "mfma_f64", "trtri_level": "mfma_f64", "chol_block": "mfma_f64",
+    "chol_syrk_ahead": "mfma_f64", "trtri_level": "mfma_f64", "chol_block": "mfma_f64", "chol_chain": "mfma_f64", "chol_rows_below": "mfma_f64",
+    "chol_panel_below": "mfma_f64",
     "gptq_window": "mfma_f64", "gptq_window_wide": "mfma_f64", "gptq_trailing": "mfma_f64",
     "error_gemm": "mfma_f32", "error_gemm_bf16": "mfma_bf16", "hessian_syrk": "mfma_f32",
 }
@@ -805,6 +806,35 @@ def main():
                 "library_gemm_result_was_symmetric": gemm_symmetric}
         del alt, alt_layers
 
+    # ---- a13, the local search alone at 10 and 100 moves (sleekit_heavy runs 100: sleekit/statistics.py:143) on one layer of
+    #      the headline's shape: the move kernel's own time (events around its launch) against its algorithmic bytes
+    search = None
+    if extras and not args.config:
+        from sleekit_amd import engine
+
+        lay = head.layers[0]
+        Ws = engine.rows_divide(lay["W"], lay["scale"])
+        base = engine.quantize_layer(lay["W"], lay["H"], head.cb, lay["scale"], "diag", 0.01, 0, unscale=False)
+        search = {"shape": list(shapes[0]), "unit": "us", "bound": "hbm", "peak_gb_s": PEAK["hbm"][0] / 1e9}
+        for mv in (10, 100):
+            for rep in range(2):  # (the second is timed)
+                Qs = base.Q.clone()
+                torch.cuda.synchronize()
+                _lib.lib.slk_profile_reset()
+                _lib.lib.slk_profile_enable(1)
+                engine.local_search(Ws, Qs, lay["H"], engine.require_uniform(head.cb), mv)
+                torch.cuda.synchronize()
+                _lib.lib.slk_profile_enable(0)
+                rep_ = {k["kernel"]: k for k in _lib.profile_report()}
+                _lib.lib.slk_profile_reset()
+            k = rep_.get("local_search")
+            if k:
+                search[f"moves_{mv}"] = {"us": round(1e3 * k["total_ms"], 1), "us_per_move": round(1e3 * k["total_ms"] / mv, 2),
+                                         "achieved_gb_s": round(k["bytes"] / (k["total_ms"] * 1e-3) / 1e9, 1),
+                                         "frac": round(k["bytes"] / (k["total_ms"] * 1e-3) / PEAK["hbm"][0], 4)}
+        search["algorithmic_bytes"] = "moves x R x 4 n (one streamed row of H per row and move) + 13 R n (state in and out), SURVEY.md 8d"
+        del Ws, base
+
     # ---- a1, Hessian accumulation, timed as its own stage: 2048-token batches into an n x n Hessian
     hess = None
     if extras:
@@ -863,7 +893,7 @@ def main():
             "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
         },
         "roofline": roofline, "cpu_baseline": cpu, "layer_error": errs[0], "layer_errors": layer_errors, "latency_ms_single_layer": latency,
-        "asymmetric_H": asym, "hessian_accumulate": hess, "golden": golden,
+        "asymmetric_H": asym, "hessian_accumulate": hess, "local_search": search, "golden": golden,
     }
     if rccl:
         line["rccl"] = rccl
@@ -883,6 +913,7 @@ def main():
         s["loop"] = {k: (loop.get(k) or {}).get("frac") for k in ("alone", "timed")} if loop else None
         s["latency_ms"] = latency["ms"] if latency else None
         s["hessian_frac"] = hess["frac"] if hess else None
+        s["ls_us"] = [(search.get(f"moves_{m}") or {}).get("us") for m in (10, 100)] if search else None
         gold = list(golden or []) + [g for leg in (line.get("configs") or {}).values() if isinstance(leg, dict) for g in (leg.get("golden") or [])]
         s["golden_ok"] = [sum(1 for g in gold if g["idx_sha_ok"] or g.get("all_recorded_near_ties")), len(gold)]
         s["mallocs_timed"] = [head_mallocs] + [leg.get("device_mallocs_while_timed") for leg in (line.get("configs") or {}).values() if isinstance(leg, dict)]

@@ -38,7 +38,7 @@ echo "lds pass done"
 python3 - "$OUT" "$TAG" "$COMMIT" <<'PY'
 import csv, glob, json, sys, collections
 out, tag, commit = sys.argv[1], sys.argv[2], sys.argv[3]
-names = {"k_chol_panel": "chol_panel", "k_panel_below": "chol_panel_below", "k_stack_rows": "stack_rows", "k_gptq_window": "gptq_window", "k_error_tiles_bf16": "error_gemm_bf16", "k_error_tiles(": "error_gemm", "k_split3": "error_split", "k_gptq_trailing": "gptq_trailing",
+names = {"k_chol_chain<false>": "chol_chain", "k_chol_chain<true>": "chol_rows_below", "k_chol_rows_below": "chol_rows_below", "k_chol_panel": "chol_panel", "k_panel_below": "chol_panel_below", "k_stack_rows": "stack_rows", "k_gptq_window": "gptq_window", "k_error_tiles_bf16": "error_gemm_bf16", "k_error_tiles(": "error_gemm", "k_split3": "error_split", "k_gptq_trailing": "gptq_trailing",
          "k_syrk_tiles": "chol_syrk_inner", "k_syrk_triangle": "chol_syrk_outer", "k_trtri_level<0>": "trtri_stage0", "k_trtri_level<1>": "trtri_stage1", "k_permute_in": "permute_in",
          "k_permute_out": "permute_out", "k_gather_reversed": "gather_reversed", "k_flip_out": "flip_out", "k_rows_divide": "rows_divide"}
 def short(kernel_name):

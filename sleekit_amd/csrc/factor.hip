@@ -1209,7 +1209,10 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
             // chip time).  Measured on whole streams, wide against narrow: headline 5257 / 5272 Mweights/s, one rank of 8
             // 3.66 / 3.61 ms per step, BLOOM-560M 5139 / 5084 -- nothing in it, and a single factorisation is 0.4 ms longer:
             // narrow stays.
-            const bool wide = opt(OPT_ROWS_BELOW_WIDE) == 1;
+            // ... EXCEPT for chains of several wide factorisations (OPT-350M / BLOOM-560M's 1024 x 4096 layers go six to eight
+            // to a chain): 4 x 56 x 8 strips are seven rounds of the chip at 45 us, the 64-row form under two at 103.
+            const int rw = opt(OPT_ROWS_BELOW_WIDE);
+            const bool wide = rw == 1 || (rw == 0 && 4 * below_tiles * batch >= 1024);
             if (below_tiles > 0 && wide)
                 SLK_RUN_W("chol_rows_below", Bd * 64.0 * below_tiles * e * e, Bd * (16.0 * 64 * below_tiles * e + 4.0 * e * e), below_tiles * batch, s,
                           k_chol_chain<true><<<dim3(below_tiles, 1, B), 256, sizeof(PanelSmem), s>>>(A, ld, K0, nb, X, info, flags, 0));

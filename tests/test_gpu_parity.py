@@ -303,6 +303,43 @@ def test_factor_panel_step_in_two_launches_is_the_one_launch_form(amd, n):
         assert torch.equal(U, two[2][1]) and int(i.item()) == 0 and torch.equal(Ub, two_b[1]), wide
 
 
+def test_chain_handoffs_under_uneven_load(amd):
+    """The chain's hand-offs (flags in memory, write-through stores, sc1 loads) with the chip busy and UNEVENLY so -- six
+    streams factor matrices of four widths over and over while two more run layer-error products and loops: every U must be
+    the one the same call gives alone (the CDNA4 guide: idle chips and uniform load hide stale reads)."""
+    dev_ = torch.device("cuda")
+    widths = [768, 1024, 1100, 2048, 3072, 4096]
+    Hs = [synth.make_layer_device(8, n, 4300 + i, dev_)["H"] for i, n in enumerate(widths)]
+    alone = []
+    for H, n in zip(Hs, widths):
+        alone.append(amd.engine.factorize(H, n, 0.01, amd.lib.ORDER_DIAG))
+        torch.cuda.synchronize()
+    batch_alone = amd.engine.factorize_batch([Hs[0]] * 5, 768, 0.01, amd.lib.ORDER_DIAG)
+    torch.cuda.synchronize()
+    L = synth.make_layer_device(2048, 2048, 4310, dev_)
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    got = [[] for _ in widths]
+    got_b = []
+    for rep in range(6):
+        for i, (H, n) in enumerate(zip(Hs, widths)):
+            with torch.cuda.stream(streams[(i + rep) % 6]):
+                got[i].append(amd.engine.factorize(H, n, 0.01, amd.lib.ORDER_DIAG))
+        with torch.cuda.stream(streams[rep % 6]):
+            got_b.append(amd.engine.factorize_batch([Hs[0]] * 5, 768, 0.01, amd.lib.ORDER_DIAG))
+        with torch.cuda.stream(streams[6]):
+            res = amd.engine.quantize_layer(L["W"], L["H"], cb, L["scale"], lookahead=False)
+        with torch.cuda.stream(streams[7]):
+            amd.engine.row_errors(L["W"], L["W"] * 0.99, L["H"])
+    torch.cuda.synchronize()
+    for i in range(len(widths)):
+        for o, U, info in got[i]:
+            assert int(info.item()) == 0 and torch.equal(o, alone[i][0]) and torch.equal(U, alone[i][1]), widths[i]
+    for o, U, info in got_b:
+        assert torch.equal(U, batch_alone[1]) and int(info.abs().sum().item()) == 0
+    assert res.Q is not None
+
+
 def test_factor_of_plain_matrix_and_not_pd(amd):
     rng = np.random.default_rng(11)
     A = rng.standard_normal((200, 150))

@@ -64,14 +64,18 @@ extern "C" {
 typedef void *slk_stream_t;
 
 /* Library / device ---------------------------------------------------------
- * slk_abi_version: 7.  History: 2 = every quantizing entry takes (levels, lo, hi, table); 3 adds the batch forms
+ * slk_abi_version: 8.  History: 2 = every quantizing entry takes (levels, lo, hi, table); 3 adds the batch forms
  * (slk_gptq_quantize_batch, slk_row_errors_batch, slk_workspace_bytes_batch) and slk_symmetry_flag; 4 adds the
  * `trace` and `gains` arguments of slk_local_search, slk_set_option / slk_get_option and the batched factorisation
  * (slk_hessian_prepare_batch, slk_chol_inverse_upper_batch, slk_factor_workspace_bytes_batch); 5 adds codebook training
  * (slk_codebook_stats, slk_sort_f32, slk_unique_f32), slk_local_search_batch and slk_factor_unpack_upper_batch; 6 adds
  * slk_chol_inverse_upper_lookahead and slk_release_helpers (the look-ahead is an argument of the call, not a process-wide switch)
  * and turns the loop's `unscale` argument into `flags` (SLK_LOOP_UNSCALE = 1 as before, SLK_LOOP_LATENCY = 2); slk_local_search(_batch)
- * gain `row_err` (the rows' errors after the moves), slk_probe_panel_cycles is new; 7 adds slk_stack_rows and the option "panel_split".   */
+ * gain `row_err` (the rows' errors after the moves), slk_probe_panel_cycles is new; 7 adds slk_stack_rows and the option "panel_split";
+ * 8: no new entry point -- the factorisation's default form is the CHAIN (an outer block's panels in one launch of workgroups that
+ * hand the panels on through flags in memory: option "panel_split" 0 / 3; 1 / 2 = round 3's panel kernels), whose status word can
+ * read SLK_INFO_HANDOFF_TIMEOUT; the factorisation's workspace holds its flags (slk_factor_workspace_bytes_batch grew by
+ * 8 * (ld / 64) bytes per matrix); new options "no_tall_error", "rows_below_wide".   */
 int slk_abi_version(void);
 const char *slk_last_error(void);
 /* Run-time switches between code paths that give the same results (the tests hold them to that) or that shape a

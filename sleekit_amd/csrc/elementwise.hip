@@ -162,7 +162,7 @@ using namespace slk;
 
 extern "C" {
 
-int slk_abi_version(void) { return 7; }
+int slk_abi_version(void) { return 8; }
 
 const char *slk_last_error(void) { return g_error; }
 

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_sizes():
     from sleekit_amd import _lib
 
-    assert _lib.lib.slk_abi_version() == 7
+    assert _lib.lib.slk_abi_version() == 8
     assert _lib.lib.slk_factor_ld(1) == 64 and _lib.lib.slk_factor_ld(64) == 64 and _lib.lib.slk_factor_ld(11008) == 11008
     assert _lib.lib.slk_factor_ld(1100) == 1152
     # 4096 x 4096: two float64 n x n scratch matrices dominate

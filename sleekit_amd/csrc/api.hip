@@ -231,6 +231,11 @@ hipError_t helper_for(hipStream_t main, int need, Helper *out) {
         HelperRec r{};
         e = hipStreamCreateWithFlags(&r.h.stream, hipStreamNonBlocking);
         if (e != hipSuccess) return e;
+        e = hipStreamCreateWithFlags(&r.h.stream2, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            (void)hipStreamDestroy(r.h.stream);
+            return e;
+        }
         r.h.events = new hipEvent_t[HELPER_EVENTS]();
         r.made = 0;
         it = g_helpers.emplace(std::make_pair(device, main), r).first;
@@ -243,6 +248,7 @@ hipError_t helper_for(hipStream_t main, int need, Helper *out) {
             while (r.made > had) (void)hipEventDestroy(r.h.events[--r.made]);
             if (had == 0) {
                 (void)hipStreamDestroy(r.h.stream);
+                (void)hipStreamDestroy(r.h.stream2);
                 delete[] r.h.events;
                 g_helpers.erase(it);
             }
@@ -269,9 +275,12 @@ static hipError_t release_helpers() {
         if (e != hipSuccess && first == hipSuccess) first = e;
         e = hipStreamSynchronize(r.h.stream);
         if (e != hipSuccess && first == hipSuccess) first = e;
+        e = hipStreamSynchronize(r.h.stream2);
+        if (e != hipSuccess && first == hipSuccess) first = e;
         if (now != kv.first.first) (void)hipSetDevice(now);
         for (int i = 0; i < r.made; ++i) (void)hipEventDestroy(r.h.events[i]);
         (void)hipStreamDestroy(r.h.stream);
+        (void)hipStreamDestroy(r.h.stream2);
         delete[] r.h.events;
     }
     g_helpers.clear();

@@ -96,7 +96,8 @@ int opt(Opt o);
 // one stream.  Fork and join are event record / wait pairs, which a hipGraph capture of the caller's stream follows.
 struct Helper {
     hipStream_t stream;
-    hipEvent_t *events;  // room for HELPER_EVENTS; the first `need` of helper_for exist
+    hipStream_t stream2;  // a second one: what the look-ahead runs beside the rest of an outer update (nodes of the inverse)
+    hipEvent_t *events;   // room for HELPER_EVENTS; the first `need` of helper_for exist
 };
 constexpr int HELPER_EVENTS = 512;
 // the helper of (current device, main) with at least `need` events (created as they are first asked for; on failure

@@ -1081,14 +1081,14 @@ __global__ __launch_bounds__(256) void k_syrk_triangle(double *__restrict__ A, i
 // blocks id, id + 256, ... that land on one CU mix depths.
 template <int STAGE>
 __global__ __launch_bounds__(256) void k_trtri_level(const double *__restrict__ L, double *__restrict__ X,
-                                                     double *__restrict__ S, int ld, int nt, int s) {
+                                                     double *__restrict__ S, int ld, int nt, int s, int node0) {
     __shared__ __attribute__((aligned(16))) Tile64Smem sm;
     L += (size_t)blockIdx.z * ld * ld;
     X += (size_t)blockIdx.z * ld * ld;
     S += (size_t)blockIdx.z * ld * ld;
     // block id -> (node, slow, fast): `fast` runs over the s tiles of the balanced direction
     const int id = blockIdx.x;
-    const int per_node = s * s, node = id / per_node, in_node = id % per_node;
+    const int per_node = s * s, node = node0 + id / per_node, in_node = id % per_node;  // (node0: a launch may cover a range of nodes)
     const int deep = in_node / s, other = in_node % s;  // deep = 0 is the deepest K range
     const int lo = node * 2 * s, mid = lo + s;
     const int bi = (STAGE == 0) ? mid + other : mid + (s - 1 - deep);
@@ -1169,8 +1169,8 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
     // (4850 -> 3560 Mweights/s on one rank whatever GPU_MAX_HW_QUEUES is, 4.7 -> 7.3 ms per step of a rank of 8).  So it
     // is a switch, off by default, which the single-layer API turns on (sleekit_amd/engine.py: quantize_layer).
     Helper helper{};
-    const bool lookahead = (want_lookahead || opt(OPT_LOOKAHEAD)) && nt >= LOOKAHEAD_MIN_TILES + OUTER / TILE && nt / (OUTER / TILE) < HELPER_EVENTS / 2;
-    if (lookahead) SLK_HIP(helper_for(s, 2 * (nt / (OUTER / TILE) + 1), &helper));  // two events per outer block
+    const bool lookahead = (want_lookahead || opt(OPT_LOOKAHEAD)) && nt >= LOOKAHEAD_MIN_TILES + OUTER / TILE && nt / (OUTER / TILE) < HELPER_EVENTS / 3;
+    if (lookahead) SLK_HIP(helper_for(s, 3 * (nt / (OUTER / TILE) + 1), &helper));  // up to three events per outer block
     // The panel step in one launch (this factorisation is alone on the GPU: its launch chain is the critical path) or in two
     // (others are in flight: the tiles below the diagonal tile must not hold their CUs while its pivot chain runs)
     // Measured on whole streams (ms per step, one launch against two): batches of small matrices gain (OPT-125M 14.50 -> 14.06,
@@ -1190,7 +1190,52 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
         SLK_LDS_OPT_IN(k_chol_chain<true>, sizeof(PanelSmem));
         SLK_LDS_OPT_IN(k_chol_rows_below, sizeof(RowsBelowSmem));
     }
+    // The inverse, level by level: level `lvl` merges the inverted halves of nodes of 2 lvl tiles (k_trtri_level).  A node can
+    // be merged as soon as its tiles are factored, so a factorisation that looks ahead hands the nodes that an outer block
+    // completes to the helper stream at once (below); what is left -- without look-ahead: everything -- follows the last block.
+    // inv_done[i]: nodes of level 2^i already launched.  Same kernels, same nodes, same K ranges: same bits.
+    // A node's FIRST stage (S = L[B, A] X[A, A]) only wants its left half inverted and the columns of that half factored:
+    // it is ready when the factorisation has passed the node's MIDDLE, half a node before the second stage (X[B, A] = -X[B, B]
+    // S), which wants the right half's inverse.  inv_done[stage][i]: nodes of level 2^i whose stage has been launched.
+    int inv_done[2][16] = {{0}, {0}};
+    auto inverse_nodes = [&](int tiles_done, hipStream_t st) -> int {
+        int li = 0;
+        for (int lvl = 1; lvl < nt; lvl *= 2, ++li) {
+            const int all = (nt + 2 * lvl - 1) / (2 * lvl);
+            for (int stage = 0; stage < 2; ++stage) {
+                int ready;
+                if (tiles_done >= nt) ready = all;
+                else if (stage == 0) ready = tiles_done >= lvl ? (tiles_done - lvl) / (2 * lvl) + 1 : 0;  // mid <= tiles_done
+                else ready = tiles_done / (2 * lvl);                                                       // hi <= tiles_done
+                if (ready > all) ready = all;
+                const int first = inv_done[stage][li], count = ready - first;
+                if (count <= 0) continue;
+                inv_done[stage][li] = ready;
+                // work of these nodes: tiles (bi in B, bj in A) with their triangular K ranges
+                double fl = 0, tiles = 0;
+                for (int nd = first; nd < ready; ++nd) {
+                    const int lo = nd * 2 * lvl, mid = lo + lvl, hi = lo + 2 * lvl < nt ? lo + 2 * lvl : nt;
+                    for (int bi = mid; bi < hi; ++bi)
+                        for (int bj = lo; bj < mid; ++bj) {
+                            fl += 2.0 * 64 * 64 * 64 * (stage == 0 ? mid - bj : bi + 1 - mid);
+                            tiles += 1;
+                        }
+                }
+                if (tiles == 0) continue;  // (a last node without a second half)
+                dim3 grid(count * lvl * lvl, 1, B);
+                if (stage == 0)
+                    SLK_RUN_W("trtri_stage0", Bd * fl, Bd * (fl / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64), tiles * batch, st,
+                              k_trtri_level<0><<<grid, 256, 0, st>>>(A, X, S, ld, nt, lvl, first));
+                else
+                    SLK_RUN_W("trtri_stage1", Bd * fl, Bd * (fl / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64), tiles * batch, st,
+                              k_trtri_level<1><<<grid, 256, 0, st>>>(A, X, S, ld, nt, lvl, first));
+            }
+        }
+        return SLK_OK;
+    };
+    const int EV = chain ? 3 : 2;  // helper events per outer block (chain: + the inverse's nodes behind the rest of the update)
     int block = 0, forked = -1;  // forked: the last block whose rest went to the helper and has not been joined
+    int inverse_on_helper = -1;  // the last block behind whose rest the helper also runs nodes of the inverse
     for (int K0 = 0; K0 < ld; K0 += OUTER) {
         const int K1 = K0 + OUTER < ld ? K0 + OUTER : ld;
         if (chain) {
@@ -1201,7 +1246,7 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
             if (below_tiles > 0 && forked >= 0) {
                 // look-ahead: the rows below read tiles that the REST of the previous block's outer update (helper stream)
                 // writes; the chain above did not -- it ran beside it
-                SLK_HIP(hipStreamWaitEvent(s, helper.events[2 * forked + 1], 0));
+                SLK_HIP(hipStreamWaitEvent(s, helper.events[EV * forked + 1], 0));
                 forked = -1;
             }
             // the rows below: 16 rows per workgroup (k_chol_rows_below: 45 us a launch at 4096 columns, most of the chip) or,
@@ -1269,11 +1314,11 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
                 // the outer update -- the rectangle under that block and the triangle beyond -- goes to the helper stream and
                 // runs beside the chain (8 CUs for ~130 us), joined before the next block's rows below are made (above).
                 // Same tiles, same K ranges, one update per tile and block in the order of the blocks (events): same bits.
-                SLK_HIP(hipEventRecord(helper.events[2 * block], s));  // this block's chain and rows below are done
+                SLK_HIP(hipEventRecord(helper.events[EV * block], s));  // this block's chain and rows below are done
                 const int nbn = ahead < m ? ahead : m, td = nbn * (nbn + 1) / 2;
                 SLK_RUN_W("chol_syrk_ahead", Bd * td * 2.0 * 64 * 64 * (K1 - K0), Bd * (16.0 * nbn * 64 * (K1 - K0) + td * 16.0 * 64 * 64), td * batch, s,
                           k_syrk_tiles<<<dim3(nbn, nbn, B), 256, 0, s>>>(A, ld, t0, t0, K0, K1));
-                SLK_HIP(hipStreamWaitEvent(helper.stream, helper.events[2 * block], 0));
+                SLK_HIP(hipStreamWaitEvent(helper.stream, helper.events[EV * block], 0));
                 const int m2 = m - nbn, total2 = m2 * (m2 + 1) / 2;
                 if (m2 > 0) {
                     SLK_RUN_W("chol_syrk_outer", Bd * (double)nbn * m2 * 2.0 * 64 * 64 * (K1 - K0), Bd * (8.0 * (ld - K1) * (K1 - K0) + (double)nbn * m2 * 16.0 * 64 * 64),
@@ -1283,8 +1328,18 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
                               (double)total2 * batch, helper.stream,
                               k_syrk_triangle<<<dim3(8 * ((total2 + 7) / 8), 1, B), 256, 0, helper.stream>>>(A, ld, t0 + nbn, m2, K0, K1));
                 }
-                SLK_HIP(hipEventRecord(helper.events[2 * block + 1], helper.stream));
+                SLK_HIP(hipEventRecord(helper.events[EV * block + 1], helper.stream));
                 forked = block;
+                // ... and beside it, on a helper stream of their own (behind the rest of the update they would hold up the next
+                // block's rows below), the nodes of the inverse that this block completes (tiles [0, K1) are factored): they
+                // read L and X tiles left of K1, which nothing writes any more
+                SLK_HIP(hipStreamWaitEvent(helper.stream2, helper.events[EV * block], 0));
+                {
+                    const int rc = inverse_nodes(t0, helper.stream2);
+                    if (rc != SLK_OK) return rc;
+                }
+                SLK_HIP(hipEventRecord(helper.events[EV * block + 2], helper.stream2));
+                inverse_on_helper = block;
             } else if (lookahead && m >= LOOKAHEAD_MIN_TILES) {
                 // LOOK-AHEAD.  Only the next outer block's columns are needed before its panels can start: those
                 // (4 m - 6 tiles) are updated here, on the caller's stream; the rest of the triangle goes to the helper
@@ -1304,8 +1359,18 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
                 forked = block;
             } else {
                 if (forked >= 0) {  // the helper's last piece touches these tiles too: join first
-                    SLK_HIP(hipStreamWaitEvent(s, helper.events[2 * forked + 1], 0));
+                    SLK_HIP(hipStreamWaitEvent(s, helper.events[EV * forked + 1], 0));
                     forked = -1;
+                }
+                if (lookahead && chain) {
+                    // (a short trailing triangle: the update stays on the caller's stream, but the nodes of the inverse that this
+                    // block completes still go to the second helper stream, beside the next chain)
+                    SLK_HIP(hipEventRecord(helper.events[EV * block], s));
+                    SLK_HIP(hipStreamWaitEvent(helper.stream2, helper.events[EV * block], 0));
+                    const int rc = inverse_nodes(t0, helper.stream2);
+                    if (rc != SLK_OK) return rc;
+                    SLK_HIP(hipEventRecord(helper.events[EV * block + 2], helper.stream2));
+                    inverse_on_helper = block;
                 }
                 SLK_RUN_W("chol_syrk_outer", Bd * tiles * 2.0 * 64 * 64 * (K1 - K0), Bd * (8.0 * (ld - K1) * (K1 - K0) + tiles * 16.0 * 64 * 64),
                           tiles * batch, s, k_syrk_triangle<<<dim3(8 * ((total + 7) / 8), 1, B), 256, 0, s>>>(A, ld, t0, m, K0, K1));
@@ -1313,25 +1378,11 @@ static int chol_inverse_impl(double *A, int batch, int n, double *U, int *info, 
         }
         ++block;
     }
-    if (forked >= 0) SLK_HIP(hipStreamWaitEvent(s, helper.events[2 * forked + 1], 0));
-    for (int lvl = 1; lvl < nt; lvl *= 2) {
-        const int nodes = (nt + 2 * lvl - 1) / (2 * lvl);
-        dim3 grid(nodes * lvl * lvl, 1, B);
-        // work of this level: for every node, tiles (bi in B, bj in A) with their triangular K ranges
-        double f0 = 0, f1 = 0, tiles = 0;
-        for (int lo = 0; lo + lvl < nt; lo += 2 * lvl) {
-            const int mid = lo + lvl, hi = lo + 2 * lvl < nt ? lo + 2 * lvl : nt;
-            for (int bi = mid; bi < hi; ++bi)
-                for (int bj = lo; bj < mid; ++bj) {
-                    f0 += 2.0 * 64 * 64 * 64 * (mid - bj);
-                    f1 += 2.0 * 64 * 64 * 64 * (bi + 1 - mid);
-                    tiles += 1;
-                }
-        }
-        SLK_RUN_W("trtri_stage0", Bd * f0, Bd * (f0 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64), tiles * batch, s,
-                  k_trtri_level<0><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
-        SLK_RUN_W("trtri_stage1", Bd * f1, Bd * (f1 / 64 * 8.0 / 2 + tiles * 8.0 * 64 * 64), tiles * batch, s,
-                  k_trtri_level<1><<<grid, 256, 0, s>>>(A, X, S, ld, nt, lvl));
+    if (forked >= 0) SLK_HIP(hipStreamWaitEvent(s, helper.events[EV * forked + 1], 0));
+    if (inverse_on_helper >= 0) SLK_HIP(hipStreamWaitEvent(s, helper.events[EV * inverse_on_helper + 2], 0));
+    {
+        const int rc = inverse_nodes(nt, s);  // every node not merged yet (without look-ahead: all of them)
+        if (rc != SLK_OK) return rc;
     }
     SLK_RUN("flip_out", 0, Bd * 12.0 * n * n, s, k_flip_out<<<dim3(n < 2048 ? n : 2048, 1, B), 256, 0, s>>>(X, ld, n, U));
     return SLK_OK;

@@ -4,6 +4,7 @@ import os
 import re
 import subprocess
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -82,6 +83,18 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert _lib.lib.slk_stack_rows(one, 1, 8, 4, 16, 0.0, 8, None) == _lib.E_ARG  # fewer padded rows than rows
     assert _lib.lib.slk_stack_rows(None, 0, 8, 8, 16, 0.0, None, None) == _lib.OK  # an empty batch is nothing to do
     assert _lib.lib.slk_set_option(b"panel_split", 0) == _lib.OK and _lib.lib.slk_get_option(b"panel_split") == 0
+    # ... with ABI version 8 (no new entry point: the chain is the factorisation's default form; its flags live in the workspace)
+    for name in (b"no_tall_error", b"rows_below_wide"):
+        assert _lib.lib.slk_set_option(name, 0) == _lib.OK and _lib.lib.slk_get_option(name) == 0
+    assert _lib.lib.slk_set_option(b"no_such_option", 1) == _lib.E_ARG
+    per_matrix = _lib.lib.slk_factor_workspace_bytes_batch(2, 4096) - _lib.lib.slk_factor_workspace_bytes_batch(1, 4096)
+    assert per_matrix >= 2 * 4096 * 4096 * 8 + 2 * 64 * 4  # X and S, and the chain's 2 x 64 flags
+    from sleekit_amd import _device as sdev
+
+    with pytest.raises(RuntimeError, match="hand-off timed out"):
+        sdev.raise_not_pd(sdev.HANDOFF_TIMEOUT, "compute_hessian_chol")
+    with pytest.raises(np.linalg.LinAlgError, match="pivot 41"):
+        sdev.raise_not_pd(42, "compute_hessian_chol")
     with pytest.raises(RuntimeError):
         _lib.check(_lib.E_ARG)
 

@@ -75,7 +75,7 @@ typedef void *slk_stream_t;
  * 8: no new entry point -- the factorisation's default form is the CHAIN (an outer block's panels in one launch of workgroups that
  * hand the panels on through flags in memory: option "panel_split" 0 / 3; 1 / 2 = round 3's panel kernels), whose status word can
  * read SLK_INFO_HANDOFF_TIMEOUT; the factorisation's workspace holds its flags (slk_factor_workspace_bytes_batch grew by
- * 8 * (ld / 64) bytes per matrix); new options "no_tall_error", "rows_below_wide".   */
+ * 8 * (ld / 64) bytes per matrix); new options "tall_error", "rows_below_wide".   */
 int slk_abi_version(void);
 const char *slk_last_error(void);
 /* Run-time switches between code paths that give the same results (the tests hold them to that) or that shape a

@@ -179,7 +179,7 @@ namespace {
 const char *const kOptNames[OPT_COUNT] = {
     "NO_FAST_LEAF", "NO_DEFER", "NO_WINDOW2", "WIN_DBG", "NO_REGULAR_SEARCH", "NO_FAST_SEARCH_DIV",
     "NO_ERROR_SPLITK", "ERROR_CB", "NO_SYM_ERROR", "NO_BF16_ERROR", "NO_BF16_DMA", "NO_BF16_HESSIAN",
-    "ERROR_F32_BELOW", "NO_BF16_ASYM", "NO_SYM_AVERAGE", "NO_WAVE_SEARCH", "LOOKAHEAD", "WINDOW_ROWS", "PANEL_SPLIT", "NO_TALL_ERROR", "ROWS_BELOW_WIDE",
+    "ERROR_F32_BELOW", "NO_BF16_ASYM", "NO_SYM_AVERAGE", "NO_WAVE_SEARCH", "LOOKAHEAD", "WINDOW_ROWS", "PANEL_SPLIT", "TALL_ERROR", "ROWS_BELOW_WIDE",
 };
 std::atomic<int> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

@@ -1068,8 +1068,13 @@ __global__ __launch_bounds__(256) void k_syrk_triangle(double *__restrict__ A, i
         [&](int k0, double(&v)[8]) { load8d<true>(pb + k0, v); });
     // (fetching the tile of C before the products, as the inner update does, costs 48 registers: 3 waves per SIMD
     // instead of 4, which this chip-wide kernel needs more than the shorter tail)
+    // The tile of C is fetched AFTER the products, but ALL of it before the first store: written as `pc[...] -= v` element by
+    // element the compiler cannot tell the sixteen addresses of a thread apart (ld is a run-time value) and emitted sixteen
+    // load -> s_waitcnt vmcnt(0) -> store round trips one behind the other -- as long as the products of a K = 512 tile.
     double *pc = A + (size_t)bi * TILE * ld + (size_t)bj * TILE;
-    tile64_foreach(acc, [&](int r, int c, double v) { pc[(size_t)r * ld + c] -= v; });
+    Acc64 old;
+    tile64_map(old, [&](int r, int c) { return pc[(size_t)r * ld + c]; });
+    tile64_foreach2(old, acc, [&](int r, int c, double o, double v) { pc[(size_t)r * ld + c] = o - v; });
 }
 
 // Level s of the inverse: nodes [lo, lo + s) u [lo + s, min(lo + 2s, nt)), lo a multiple of 2s.

@@ -684,6 +684,18 @@ __global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, c
                 load8d_cols_guarded(U + (size_t)min(k, kb - 1) * n + j0, b_c2, jb - 1 - j0, k < kb, v);
             });
     }
+    if (r0 + TILE <= R && j0 + TILE <= jb) {
+        // interior tile: ALL sixteen old values of a thread first, then the sixteen stores.  Element by element (below) every
+        // guarded `*p = *p - v` is a load -> s_waitcnt vmcnt(0) -> store round trip of its own, sixteen in a row at the end of
+        // every tile: the compiler cannot tell the addresses apart.
+        float *q0 = Qp + (size_t)r0 * n + j0;
+        float oldq[16];
+        int e = 0;
+        tile64_foreach(acc, [&](int r, int c, double) { oldq[e++] = q0[(size_t)r * n + c]; });
+        e = 0;
+        tile64_foreach(acc, [&](int r, int c, double v) { q0[(size_t)r * n + c] = (float)((double)oldq[e++] - v); });
+        return;
+    }
     tile64_foreach(acc, [&](int r, int c, double v) {
         if (r0 + r < R && j0 + c < jb) {
             float *p = Qp + (size_t)(r0 + r) * n + j0 + c;

@@ -324,24 +324,40 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
+    // (epilogue as in k_error_tiles_bf16_tall: the differences of half a sub-tile fetched together -- rows beyond R read the
+    // last row and count for nothing --, the sixteen row sums down the lane tree side by side)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        float dd[16][2], sv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float s = 0.0f;
+            const bool live = r0 + row < R;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int col = j0 + wc * 64 + j * 32 + (lane & 31);
-                if (r0 + row < R) {
-                    const size_t o = (size_t)(r0 + row) * n + col;
-                    if (G) G[o] = acc.c[i][j][r];
-                    s = s + acc.c[i][j][r] * (W[o] - Q[o]);
-                }
+                const size_t o = (size_t)min(r0 + row, R - 1) * n + j0 + wc * 64 + j * 32 + (lane & 31);
+                dd[r][j] = W[o] - Q[o];
+                if (G && live) G[o] = acc.c[i][j][r];
             }
+        }
 #pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
-            if ((lane & 31) == 0) rowpart[wc][row] = s;
+        for (int r = 0; r < 16; ++r) {
+            const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float sacc = 0.0f;
+            if (r0 + row < R) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) sacc = sacc + acc.c[i][j][r] * dd[r][j];
+            }
+            sv[r] = sacc;
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = sv[r] + __shfl_xor(sv[r], m, 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if ((lane & 31) == 0) rowpart[wc][row] = sv[r];
         }
     }
     __syncthreads();
@@ -351,8 +367,9 @@ __global__ __launch_bounds__(256) void k_error_tiles_bf16(const float *__restric
 
 // The same product on 256 x 128 tiles (mfma_bf16x3.h: tile256_mac): 512 threads, two 128-row slabs of D against one slab
 // of H per round.  Same column tiles, same rounds, same epilogue per 64 x 64 sub-tile: every partial sum is the 128 x 128
-// kernel's bit for bit (tests/test_gpu_parity.py::test_layer_error_bf16_path compares the two).  Taken for whole layers
-// (at least 2048 rows, a multiple of 256; no K chunks); everything else stays on the kernel above.
+// kernel's bit for bit (tests/test_gpu_parity.py::test_layer_error_on_tall_tiles_is_the_square_tile_kernel).  An option for whole
+// layers (at least 2048 rows, a multiple of 256; no K chunks): measured 1-5 % ahead of the square tiles before the epilogues of
+// both were batched, behind them since (one workgroup per CU: nothing runs under its epilogue).
 constexpr int TALL = 256;
 __global__ __launch_bounds__(512) void k_error_tiles_bf16_tall(const float *__restrict__ W, const float *__restrict__ Q,
                                                                   const unsigned short *__restrict__ Dp, const unsigned short *__restrict__ Hp,
@@ -402,22 +419,37 @@ __global__ __launch_bounds__(512) void k_error_tiles_bf16_tall(const float *__re
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
+    // (epilogue: the 32 differences W - Q of a half of the sub-tile are fetched TOGETHER, then the sixteen row sums go down the
+    // lane tree side by side -- row by row, four loads -> wait -> five dependent shuffles each, the tail of a tile was 32
+    // trips to memory one behind the other.  Same products, same additions in the same order.)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        float dd[16][2], sv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float s = 0.0f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int col = j0 + wc * 64 + j * 32 + (lane & 31);
-                const size_t o = (size_t)(r0 + row) * n + col;
+                const size_t o = (size_t)(r0 + row) * n + j0 + wc * 64 + j * 32 + (lane & 31);
+                dd[r][j] = W[o] - Q[o];
                 if (G) G[o] = acc.c[i][j][r];
-                s = s + acc.c[i][j][r] * (W[o] - Q[o]);
             }
+        }
 #pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, 64);
-            if ((lane & 31) == 0) rowpart[wc][row] = s;
+        for (int r = 0; r < 16; ++r) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) sacc = sacc + acc.c[i][j][r] * dd[r][j];
+            sv[r] = sacc;
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = sv[r] + __shfl_xor(sv[r], m, 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if ((lane & 31) == 0) rowpart[wc][row] = sv[r];
         }
     }
     __syncthreads();
@@ -604,6 +636,9 @@ __global__ __launch_bounds__(256) void k_hessian_tiles_bf16(float *__restrict__ 
     else
         tile128_mac_planes(acc, sm, 0, ksteps * 32, la, lb);
     const int i0 = bi * T32, j0 = bj * T32;
+    // (the 64 read-modify-writes of a thread come out as 64 load -> wait -> store round trips one behind the other; fetching
+    // the old values first was measured: 310 against 300 us per 2048 tokens -- 256 VGPRs, and two workgroups per CU hide the
+    // tail as it is)
     tile128_foreach(acc, [&](int r, int c, float v) {
         const int i = i0 + r, j = j0 + c;
         if (bi != bj || j <= i) {
@@ -742,8 +777,10 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
         // flops as executed: six bfloat16 products per float32 product, over k <= j only (the definition of the
         // layer error, SURVEY.md 8d, counts 2 R n^2 float32 flops: a third of this, twice over)
         const int wgs = cb > 0 ? n_rt * n_slots : 8 * ((n_rt + 7) / 8) * ((n_tiles + 7) / 8 * 8);  // see the tile order in the kernel
-        // whole layers: 256 x 128 tiles (see k_error_tiles_bf16_tall; "no_tall_error" = 1 keeps the 128 x 128 kernel)
-        const bool tall = dma && cb == 0 && R % TALL == 0 && rpl % TALL == 0 && R / TALL >= 8 && !opt(OPT_NO_TALL_ERROR);
+        // whole layers on 256 x 128 tiles: an option ("tall_error" = 1, see k_error_tiles_bf16_tall).  It led by 1-5 % until the
+        // epilogues were batched (round 4); since then the square tiles, two workgroups to a CU so that one's epilogue runs
+        // under the other's MFMAs, are ahead (451 against 489 us on one box).
+        const bool tall = dma && cb == 0 && R % TALL == 0 && rpl % TALL == 0 && R / TALL >= 8 && opt(OPT_TALL_ERROR) == 1;
         if (tall) {
             SLK_LDS_OPT_IN(k_error_tiles_bf16_tall, sizeof(TileBf16TallSmem));
             const int wgs_tall = 8 * ((R / TALL + 7) / 8) * ((n_tiles + 7) / 8 * 8);

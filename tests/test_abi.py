@@ -84,7 +84,7 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert _lib.lib.slk_stack_rows(None, 0, 8, 8, 16, 0.0, None, None) == _lib.OK  # an empty batch is nothing to do
     assert _lib.lib.slk_set_option(b"panel_split", 0) == _lib.OK and _lib.lib.slk_get_option(b"panel_split") == 0
     # ... with ABI version 8 (no new entry point: the chain is the factorisation's default form; its flags live in the workspace)
-    for name in (b"no_tall_error", b"rows_below_wide"):
+    for name in (b"tall_error", b"rows_below_wide"):
         assert _lib.lib.slk_set_option(name, 0) == _lib.OK and _lib.lib.slk_get_option(name) == 0
     assert _lib.lib.slk_set_option(b"no_such_option", 1) == _lib.E_ARG
     per_matrix = _lib.lib.slk_factor_workspace_bytes_batch(2, 4096) - _lib.lib.slk_factor_workspace_bytes_batch(1, 4096)

@@ -586,8 +586,8 @@ def test_integration_stub_runs(amd):
 
 
 def test_layer_error_on_tall_tiles_is_the_square_tile_kernel(amd, slkopt):
-    """Whole layers (>= 2048 rows) take 256 x 128 tiles on the bfloat16 MFMA (k_error_tiles_bf16_tall: two images of a round in
-    LDS, half the workgroups); smaller ones and K-chunked shards stay on 128 x 128.  Same slabs, same six products per element,
+    """Whole layers (>= 2048 rows) CAN take 256 x 128 tiles on the bfloat16 MFMA (option tall_error; k_error_tiles_bf16_tall: two
+    images of a round in LDS, half the workgroups); the default, smaller ones and K-chunked shards are 128 x 128.  Same slabs, same six products per element,
     same rounds: the row errors and the product G = (W - Q) H are the square-tile kernel's BIT FOR BIT -- symmetric H (half
     the products), an H that is not symmetric (averaged planes), the full product for the local search, and a stack of layers."""
     rng = np.random.default_rng(23)
@@ -601,10 +601,10 @@ def test_layer_error_on_tall_tiles_is_the_square_tile_kernel(amd, slkopt):
     Hs, Has = torch.from_numpy(H).cuda(), torch.from_numpy(Ha).cuda()
 
     def both(fn):
-        tall = fn()
-        slkopt.setenv("SLK_NO_TALL_ERROR", "1")
         square = fn()
-        slkopt.delenv("SLK_NO_TALL_ERROR")
+        slkopt.setenv("SLK_TALL_ERROR", "1")
+        tall = fn()
+        slkopt.delenv("SLK_TALL_ERROR")
         return tall, square
 
     for Hx in (Hs, Has):

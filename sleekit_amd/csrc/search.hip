@@ -26,9 +26,21 @@ struct Best {
     float q;  // the row's current value at column j (saves a broadcast once the move is chosen)
 };
 __device__ __forceinline__ Best better(Best a, Best b) {
-    // larger value wins; on a tie the smaller column (first occurrence)
-    if (b.v > a.v || (b.v == a.v && b.j < a.j)) return b;
-    return a;
+    // larger value wins; on a tie the smaller column (first occurrence).  Bit-wise on purpose: with || and && hipcc builds
+    // a branch region (two exec-mask saves and a jump) around every one of the 32 comparisons of a move
+    const bool take = (b.v > a.v) | ((b.v == a.v) & (b.j < a.j));
+    Best r;
+    r.v = take ? b.v : a.v;
+    r.j = take ? b.j : a.j;
+    r.q = take ? b.q : a.q;
+    return r;
+}
+// a thread's own slots come in increasing column order: a strictly larger value is the only way to replace the first maximum
+__device__ __forceinline__ void pick_first_max(Best &b, float v, int j, float q) {
+    const bool take = v > b.v;
+    b.v = take ? v : b.v;
+    b.j = take ? j : b.j;
+    b.q = take ? q : b.q;
 }
 // Cross-lane steps on the vector ALU (DPP) instead of the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32: ~150 cycles
 // each, six dependent levels per reduction, three reductions per move -- a third of a move's time).  A butterfly level only
@@ -58,30 +70,35 @@ __device__ __forceinline__ float wave_sum_tree(float acc) {
     return (r0 + r1) + (r2 + r3);
 }
 
+__device__ __forceinline__ float max_sel(float a, float b) { return b > a ? b : a; }  // (no NaN among gains; -inf pads)
+// The wave's winner, the same on every lane: the largest value (a maximum is exact in any order), then -- the rule is a
+// total order on (value, column) -- the smallest column among the lanes that hold it.  Almost always ONE lane holds it: its
+// column and q are read off that lane; only a tie between lanes pays a second reduction.
 __device__ __forceinline__ Best wave_best(Best x) {
-#define SLK_BEST_LEVEL(CTRL)                                                      \
-    {                                                                             \
-        Best o;                                                                   \
-        o.v = dpp_f<CTRL>(x.v);                                                   \
-        o.j = dpp_i<CTRL>(x.j);                                                   \
-        o.q = dpp_f<CTRL>(x.q);                                                   \
-        x = better(x, o);                                                         \
+    float m = x.v;
+    m = max_sel(m, dpp_f<DPP_XOR1>(m));
+    m = max_sel(m, dpp_f<DPP_XOR2>(m));
+    m = max_sel(m, dpp_f<DPP_HALF_MIRROR>(m));
+    m = max_sel(m, dpp_f<DPP_MIRROR>(m));
+    m = max_sel(max_sel(lane_f(m, 0), lane_f(m, 16)), max_sel(lane_f(m, 32), lane_f(m, 48)));
+    const bool holds = x.v == m;
+    const unsigned long long who = __builtin_amdgcn_ballot_w64(holds);
+    Best r;
+    r.v = m;
+    int lane = (int)__builtin_ctzll(who | (1ull << 63));  // (who is never empty: some lane holds the maximum)
+    if (__builtin_popcountll(who) > 1) {  // wave-uniform
+        int j = holds ? x.j : 0x7fffffff;
+        j = min(j, dpp_i<DPP_XOR1>(j));
+        j = min(j, dpp_i<DPP_XOR2>(j));
+        j = min(j, dpp_i<DPP_HALF_MIRROR>(j));
+        j = min(j, dpp_i<DPP_MIRROR>(j));
+        j = min(min(__builtin_amdgcn_readlane(j, 0), __builtin_amdgcn_readlane(j, 16)),
+                min(__builtin_amdgcn_readlane(j, 32), __builtin_amdgcn_readlane(j, 48)));
+        lane = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(holds && x.j == j) | (1ull << 63));
     }
-    SLK_BEST_LEVEL(DPP_XOR1)
-    SLK_BEST_LEVEL(DPP_XOR2)
-    SLK_BEST_LEVEL(DPP_HALF_MIRROR)
-    SLK_BEST_LEVEL(DPP_MIRROR)
-#undef SLK_BEST_LEVEL
-    // the four rows' winners (every lane of a row holds its row's): a total order (value, then column), so any order of
-    // comparisons gives the same winner
-    Best r[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        r[k].v = lane_f(x.v, 16 * k);
-        r[k].j = __builtin_amdgcn_readlane(x.j, 16 * k);
-        r[k].q = lane_f(x.q, 16 * k);
-    }
-    return better(better(r[0], r[1]), better(r[2], r[3]));
+    r.j = __builtin_amdgcn_readlane(x.j, lane);
+    r.q = lane_f(x.q, lane);
+    return r;
 }
 
 __global__ void k_extract_diag(PtrTable hs, int n, float *__restrict__ d) {  // blockIdx.y: the layer of a stack
@@ -91,12 +108,15 @@ __global__ void k_extract_diag(PtrTable hs, int n, float *__restrict__ d) {  // 
 
 // trace (may be NULL): moves ints per row, 2 * column + (1 = up, 0 = down) of every move taken, -1 from the
 // first move on at which the row had nothing left to gain (or only a "move" onto the value it already has).
-template <int EPT>
+// TABLE: a general codebook (binary searches); false: the uniform grid alone -- as one kernel every one of a move's candidate
+// computations sat between two jumps on g.table.
+template <int EPT, bool TABLE>
 __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ W, float *__restrict__ Q,
                                                       PtrTable hs, int rpl, const float *__restrict__ G,
                                                       const float *__restrict__ hdiag, int R, int n, Grid g,
                                                       int moves, uint8_t *__restrict__ idx, int *__restrict__ trace,
                                                       float *__restrict__ gains, int gains_mode, float *__restrict__ row_err) {
+    if (!TABLE) g.table = nullptr;
     // (a stack of layers by rows: rows [b rpl, (b + 1) rpl) search against Hessian b)
     const float *__restrict__ H = hs.p[blockIdx.x / rpl];
     hdiag += (size_t)(blockIdx.x / rpl) * n;
@@ -110,13 +130,20 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 
     heap_sum_plan(plan, n);
 
-    float w[EPT], q[EPT], gu[EPT], gd[EPT];
+    // du / dd: the steps to a column's candidates, cand_up(q) - q and cand_down(q) - q (obq.py:257-258): pure functions of q,
+    // so they change with the moved column only.  Short rows keep them in registers (KEEP); recomputed per element and move
+    // (a true division each) they were half of the kernel's vector instructions.
+    constexpr bool KEEP = EPT <= 8;
+    float w[EPT], q[EPT], gu[EPT], gd[EPT], du[KEEP ? EPT : 1], dd[KEEP ? EPT : 1];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int j = t + 256 * e;
         if (j < n) {
             w[e] = W[base + j];
             q[e] = Q[base + j];
+            const float su = cand_up(q[e], g) - q[e];
+            const float sd = cand_down(q[e], g) - q[e];
+            if (KEEP) du[e] = su, dd[e] = sd;
             if (gains_mode == 2) {
                 // carried over from an earlier call (the stateful LocalSearchQuantizer, obq.py:234-346): the gains as
                 // the reference holds them between two do_move() calls, incrementally updated, not rebuilt
@@ -124,15 +151,14 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
                 gd[e] = gains[2 * base + n + j];
             } else {
                 const float gj = G[base + j], hjj = hdiag[j];
-                const float du = cand_up(q[e], g) - q[e];
-                const float dd = cand_down(q[e], g) - q[e];
                 // -D^2 * H_jj - 2 * (delta @ H)_j * D  with (delta @ H)_j = -G_j     (obq.py:229-231)
-                gu[e] = (-(du * du)) * hjj + (2.0f * gj) * du;
-                gd[e] = (-(dd * dd)) * hjj + (2.0f * gj) * dd;
+                gu[e] = (-(su * su)) * hjj + (2.0f * gj) * su;
+                gd[e] = (-(sd * sd)) * hjj + (2.0f * gj) * sd;
             }
         } else {
             w[e] = q[e] = 0.0f;
             gu[e] = gd[e] = NEG;
+            if (KEEP) du[e] = dd[e] = 0.0f;
         }
     }
 
@@ -146,8 +172,8 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int j = t + 256 * e;
-            if (gu[e] > bu.v) bu = {gu[e], j, q[e]};
-            if (gd[e] > bd.v) bd = {gd[e], j, q[e]};
+            pick_first_max(bu, gu[e], j, q[e]);
+            pick_first_max(bd, gd[e], j, q[e]);
         }
         bu = wave_best(bu);
         bd = wave_best(bd);
@@ -181,6 +207,7 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         //      off the moved column
         const float *hrow = H + (size_t)c * n;
         const float two_dq = 2.0f * (q_old - q_new);
+        const float hd = hdiag[c];  // asked for with the row: after the sum it would be a second trip to memory per move
 
         float h_cc = 0.0f;
 #pragma unroll
@@ -193,8 +220,8 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
                     h_cc = h;
                 } else {
                     const float f = two_dq * h;
-                    gu[e] = gu[e] + f * (cand_up(q[e], g) - q[e]);
-                    gd[e] = gd[e] + f * (cand_down(q[e], g) - q[e]);
+                    gu[e] = gu[e] + f * (KEEP ? du[e] : cand_up(q[e], g) - q[e]);
+                    gd[e] = gd[e] + f * (KEEP ? dd[e] : cand_down(q[e], g) - q[e]);
                 }
             }
         }
@@ -205,11 +232,11 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         if (t == ct) {
             const float d1u = cand_up(q_old, g) - q_old, d2u = cand_up(q_new, g) - q_new;
             const float d1d = cand_down(q_old, g) - q_old, d2d = cand_down(q_new, g) - q_new;
-            const float hd = hdiag[c];
             const float f = two_dq * h_cc;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 if (e == ce) {
+                    if (KEEP) du[e] = d2u, dd[e] = d2d;
                     float x = gu[e];
                     x = x + hd * (d1u * d1u - d2u * d2u);
                     x = x + (2.0f * s) * (d1u - d2u);
@@ -256,12 +283,17 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 // thread t, register set s holds chain t + 256 s; a wave's 8 leaves are a sub-tree of NumPy's recursion, the four waves'
 // sums meet in LDS as (T0 + T1) + (T2 + T3).  Two barriers per move (best move, sum) against the general kernel's five,
 // and no staging of the products: 684 -> 532 us for 4096 x 4096 with 10 moves, 242 -> 184 for 1024 x 4096.
-template <int M8, int S, int WAVES>
+// KEEP: the candidate steps du / dd stay in registers (see k_local_search); for the one-wave-per-row form, which is bound by
+// the issue of its instructions (4096 x 1024, 10 moves: 150 -> 113 us).  The workgroup-per-row form is bound by the LATENCY of
+// a move (one trip to memory for the row of H, two barriers), which more resident rows hide and more registers do not
+// (1024 x 4096: 121 -> 132 us with them): it recomputes.
+template <int M8, int S, int WAVES, bool TABLE>
 __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restrict__ W, float *__restrict__ Q,
                                                            PtrTable hs, int rpl, const float *__restrict__ G,
                                                            const float *__restrict__ hdiag, int R, int n, Grid g, int moves,
                                                            uint8_t *__restrict__ idx, int *__restrict__ trace,
                                                            float *__restrict__ gains, int gains_mode, float *__restrict__ row_err) {
+    if (!TABLE) g.table = nullptr;
     constexpr int EPT = M8 * S;
     __shared__ Best red_up[4], red_dn[4];
     __shared__ float red_s[2][4];
@@ -280,21 +312,26 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
 #pragma unroll
         for (int i = 0; i < M8; ++i) col[s2 * M8 + i] = ((tr >> 3) + 8 * WAVES * s2) * m + (tr & 7) + 8 * i;
 
-    float w[EPT], q[EPT], gu[EPT], gd[EPT];
+    // du / dd: the steps to the row's candidates, cand_up(q) - q and cand_down(q) - q (obq.py:257-258): pure functions of q, so
+    // they change with the moved column only.  Recomputed per element and move they were most of the kernel's instructions
+    // (a true division each: the search is bound by the ISSUE of its vector instructions, four waves a SIMD)
+    constexpr bool KEEP = WAVES == 1 && S == 1;
+    float w[EPT], q[EPT], gu[EPT], gd[EPT], du[KEEP ? EPT : 1], dd[KEEP ? EPT : 1];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int j = col[e];
         w[e] = W[base + j];
         q[e] = Q[base + j];
+        const float su = cand_up(q[e], g) - q[e];
+        const float sd = cand_down(q[e], g) - q[e];
+        if (KEEP) du[e] = su, dd[e] = sd;
         if (gains_mode == 2) {
             gu[e] = gains[2 * base + j];
             gd[e] = gains[2 * base + n + j];
         } else {
             const float gj = G[base + j], hjj = hdiag[j];
-            const float du = cand_up(q[e], g) - q[e];
-            const float dd = cand_down(q[e], g) - q[e];
-            gu[e] = (-(du * du)) * hjj + (2.0f * gj) * du;
-            gd[e] = (-(dd * dd)) * hjj + (2.0f * gj) * dd;
+            gu[e] = (-(su * su)) * hjj + (2.0f * gj) * su;
+            gd[e] = (-(sd * sd)) * hjj + (2.0f * gj) * sd;
         }
     }
 
@@ -306,9 +343,9 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
         Best bu = {NEG, 0x7fffffff, 0.0f}, bd = {NEG, 0x7fffffff, 0.0f};
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            // (a lane's columns do not come in increasing order across its register sets: ties by column, like np.argmax)
-            bu = better(bu, Best{gu[e], col[e], q[e]});
-            bd = better(bd, Best{gd[e], col[e], q[e]});
+            // (a thread's columns increase with e: within a leaf by 8, and the second register set's leaves lie 8 WAVES further)
+            pick_first_max(bu, gu[e], col[e], q[e]);
+            pick_first_max(bd, gd[e], col[e], q[e]);
         }
         bu = wave_best(bu);
         bd = wave_best(bd);
@@ -333,6 +370,7 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
 
         const float *hrow = H + (size_t)c * n;
         const float two_dq = 2.0f * (q_old - q_new);
+        const float hd = hdiag[c];  // asked for with the row: after the sum it would be a second trip to memory per move
         float h_cc = 0.0f, total = 0.0f;  // h_cc: H[c][c], met by the lane that owns column c
 #pragma unroll
         for (int s2 = 0; s2 < S; ++s2) {
@@ -347,8 +385,8 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
                     h_cc = h;
                 } else {
                     const float f = two_dq * h;
-                    gu[e] = gu[e] + f * (cand_up(q[e], g) - q[e]);
-                    gd[e] = gd[e] + f * (cand_down(q[e], g) - q[e]);
+                    gu[e] = gu[e] + f * (KEEP ? du[e] : cand_up(q[e], g) - q[e]);
+                    gd[e] = gd[e] + f * (KEEP ? dd[e] : cand_down(q[e], g) - q[e]);
                 }
             }
             // the leaf (8 accumulators = 8 lanes), then the 8 leaves of this register set
@@ -368,7 +406,6 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
                 const float hc = h_cc;
                 const float d1u = cand_up(q_old, g) - q_old, d2u = cand_up(q_new, g) - q_new;
                 const float d1d = cand_down(q_old, g) - q_old, d2d = cand_down(q_new, g) - q_new;
-                const float hd = hdiag[c];
                 const float f = two_dq * hc;
                 float x = gu[e];
                 x = x + hd * (d1u * d1u - d2u * d2u);
@@ -381,6 +418,7 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
                 y = y + f * d2d;
                 gd[e] = y;
                 q[e] = q_new;
+                if (KEEP) du[e] = d2u, dd[e] = d2d;
             }
         }
     }
@@ -435,11 +473,16 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
     const Grid g = make_grid(levels, lo, hi, table);
     const int ept = (n + 255) / 256;
     const size_t lds = (size_t)(n + 8 * (n / 128) + 8) * sizeof(float);  // heap_sum_floats(n)
+#define SLK_LS_T(E, T)                                                                                              \
+    do {                                                                                                            \
+        SLK_LDS_OPT_IN((k_local_search<E, T>), lds);                                                                \
+        SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                       \
+                (k_local_search<E, T><<<R, 256, lds, s>>>(W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode, row_err_out))); \
+    } while (0)
 #define SLK_LS(E)                                                                                                   \
     do {                                                                                                            \
-        SLK_LDS_OPT_IN(k_local_search<E>, lds);                                                                     \
-        SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                       \
-                k_local_search<E><<<R, 256, lds, s>>>(W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode, row_err_out)); \
+        if (g.table) SLK_LS_T(E, true);                                                                             \
+        else SLK_LS_T(E, false);                                                                                    \
     } while (0)
     // regular row lengths (8 or 16 leaves of m <= 128 elements, m % 8 == 0): one wave per row, no LDS, no barrier
     {
@@ -455,11 +498,14 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
         const int wave_opt = opt(OPT_NO_WAVE_SEARCH);  // 1: never, -1: whenever the row length allows (tests)
         regular = regular && m % 8 == 0 && m >= 8 && wave_opt <= 0;
         const int m8 = m / 8;
+#define SLK_LSW_T(M8, S, WAVES, T)                                                                                      \
+    SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                               \
+            (k_local_search_wave<M8, S, WAVES, T><<<WAVES == 1 ? (R + 3) / 4 : R, 256, 0, s>>>(                         \
+                W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode, row_err_out)))
 #define SLK_LSW(M8, S, WAVES, LEAVES)                                                                                   \
     if (regular && m8 == M8 && leaves == LEAVES) {                                                                      \
-        SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                           \
-                k_local_search_wave<M8, S, WAVES><<<WAVES == 1 ? (R + 3) / 4 : R, 256, 0, s>>>(                         \
-                    W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode, row_err_out));              \
+        if (g.table) SLK_LSW_T(M8, S, WAVES, true);                                                                     \
+        else SLK_LSW_T(M8, S, WAVES, false);                                                                            \
         return SLK_OK;                                                                                                  \
     }
         if (R >= 2048 || wave_opt < 0) {  // a wave per row: 8 or 16 leaves
@@ -474,6 +520,7 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
         SLK_LSW(16, 2, 4, 64)  // n = 8192
         SLK_LSW(12, 2, 4, 64)  // n = 6144
 #undef SLK_LSW
+#undef SLK_LSW_T
     }
     if (ept <= 4) SLK_LS(4);
     else if (ept <= 8) SLK_LS(8);
@@ -482,6 +529,7 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
     else if (ept <= 48) SLK_LS(48);
     else SLK_LS(64);
 #undef SLK_LS
+#undef SLK_LS_T
     return SLK_OK;
 }
 

@@ -106,11 +106,57 @@ __global__ void k_extract_diag(PtrTable hs, int n, float *__restrict__ d) {  // 
     if (i < n) d[(size_t)blockIdx.y * n + i] = hs.p[blockIdx.y][(size_t)i * n + i];
 }
 
+// The steps to a column's candidates, cand_up(q) - q and cand_down(q) - q (obq.py:257-258), are pure functions of q: they
+// change with the moved column only.  Recomputed per element and move (a true division each) they were half of a move's
+// vector instructions.  CAND = 1 keeps them as floats (short rows, where registers are free); CAND = 2, uniform grids of
+// <= 256 levels, keeps the candidates' LEVELS, four a register -- computed once by the reference's own formula
+// (codebook.py:71-86), so exact for any Q -- and forms a step as (level * step + zero) - q, the grid value as the reference
+// forms it (v_cvt_f32_ubyte, multiply, add, subtract); CAND = 0 recomputes.
+__device__ __forceinline__ float byte_as_float(unsigned pk, int k) { return (float)((pk >> (8 * k)) & 0xffu); }
+__device__ __forceinline__ unsigned byte_set(unsigned pk, int k, unsigned v) { return (pk & ~(0xffu << (8 * k))) | (v << (8 * k)); }
+template <int EPT, int CAND>
+struct Steps {
+    float du[CAND == 1 ? EPT : 1], dd[CAND == 1 ? EPT : 1];
+    unsigned pu[CAND == 2 ? (EPT + 3) / 4 : 1], pd[CAND == 2 ? (EPT + 3) / 4 : 1];
+    __device__ __forceinline__ void clear() {
+        if (CAND == 2) {
+#pragma unroll
+            for (int k = 0; k < (EPT + 3) / 4; ++k) pu[k] = pd[k] = 0u;
+        }
+    }
+    // slot E of a row whose value there is qv: the steps (up, down), kept as CAND says
+    __device__ __forceinline__ void set(int E, float qv, const Grid g, float &su, float &sd) {  // E: constant once unrolled
+        if (CAND == 2) {
+            const float tu = grid_pos(qv, g, 1.0f, 1.0f, g.top), td = grid_pos(qv, g, -1.0f, 0.0f, g.top - 1.0f);
+            pu[E / 4] = byte_set(pu[E / 4], E % 4, (unsigned)tu);
+            pd[E / 4] = byte_set(pd[E / 4], E % 4, (unsigned)td);
+            su = grid_val(tu, g) - qv;
+            sd = grid_val(td, g) - qv;
+        } else {
+            su = cand_up(qv, g) - qv;
+            sd = cand_down(qv, g) - qv;
+            if (CAND == 1) du[E] = su, dd[E] = sd;
+        }
+    }
+    __device__ __forceinline__ void get(int E, float qv, const Grid g, float &su, float &sd) const {
+        if (CAND == 2) {
+            su = grid_val(byte_as_float(pu[E / 4], E % 4), g) - qv;
+            sd = grid_val(byte_as_float(pd[E / 4], E % 4), g) - qv;
+        } else if (CAND == 1) {
+            su = du[E];
+            sd = dd[E];
+        } else {
+            su = cand_up(qv, g) - qv;
+            sd = cand_down(qv, g) - qv;
+        }
+    }
+};
+
 // trace (may be NULL): moves ints per row, 2 * column + (1 = up, 0 = down) of every move taken, -1 from the
 // first move on at which the row had nothing left to gain (or only a "move" onto the value it already has).
 // TABLE: a general codebook (binary searches); false: the uniform grid alone -- as one kernel every one of a move's candidate
 // computations sat between two jumps on g.table.
-template <int EPT, bool TABLE>
+template <int EPT, bool TABLE, int CAND>
 __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ W, float *__restrict__ Q,
                                                       PtrTable hs, int rpl, const float *__restrict__ G,
                                                       const float *__restrict__ hdiag, int R, int n, Grid g,
@@ -130,20 +176,17 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 
     heap_sum_plan(plan, n);
 
-    // du / dd: the steps to a column's candidates, cand_up(q) - q and cand_down(q) - q (obq.py:257-258): pure functions of q,
-    // so they change with the moved column only.  Short rows keep them in registers (KEEP); recomputed per element and move
-    // (a true division each) they were half of the kernel's vector instructions.
-    constexpr bool KEEP = EPT <= 8;
-    float w[EPT], q[EPT], gu[EPT], gd[EPT], du[KEEP ? EPT : 1], dd[KEEP ? EPT : 1];
+    float w[EPT], q[EPT], gu[EPT], gd[EPT];
+    Steps<EPT, CAND> st;
+    st.clear();
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int j = t + 256 * e;
         if (j < n) {
             w[e] = W[base + j];
             q[e] = Q[base + j];
-            const float su = cand_up(q[e], g) - q[e];
-            const float sd = cand_down(q[e], g) - q[e];
-            if (KEEP) du[e] = su, dd[e] = sd;
+            float su, sd;
+            st.set(e, q[e], g, su, sd);
             if (gains_mode == 2) {
                 // carried over from an earlier call (the stateful LocalSearchQuantizer, obq.py:234-346): the gains as
                 // the reference holds them between two do_move() calls, incrementally updated, not rebuilt
@@ -158,7 +201,8 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         } else {
             w[e] = q[e] = 0.0f;
             gu[e] = gd[e] = NEG;
-            if (KEEP) du[e] = dd[e] = 0.0f;
+            float su, sd;
+            st.set(e, 0.0f, g, su, sd);
         }
     }
 
@@ -209,20 +253,30 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         const float two_dq = 2.0f * (q_old - q_new);
         const float hd = hdiag[c];  // asked for with the row: after the sum it would be a second trip to memory per move
 
-        float h_cc = 0.0f;
+        // All loads of (a chunk of) the row are issued before the first is waited for, and the slots then run the same
+        // instructions, selects instead of jumps: with `if (j == c) ... else ...` per slot hipcc put every load in a block
+        // of its own, right in front of its use -- sixteen trips to memory one after the other per move.  A slot beyond the
+        // row reads the row's last element; its gains stay -inf under any finite update.  The moved column's own slot keeps
+        // its gains here (rebuilt below).
+        constexpr int CHUNK = EPT < 16 ? EPT : 16;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int j = t + 256 * e;
-            if (j < n) {
-                const float h = hrow[j];
-                terms[heap_sum_pos(j)] = (q[e] - w[e]) * h;  // Q still holds the old value at column c
-                if (j == c) {
-                    h_cc = h;
-                } else {
-                    const float f = two_dq * h;
-                    gu[e] = gu[e] + f * (KEEP ? du[e] : cand_up(q[e], g) - q[e]);
-                    gd[e] = gd[e] + f * (KEEP ? dd[e] : cand_down(q[e], g) - q[e]);
-                }
+        for (int e0 = 0; e0 < EPT; e0 += CHUNK) {
+            float h[CHUNK];
+#pragma unroll
+            for (int k = 0; k < CHUNK; ++k) h[k] = hrow[min(t + 256 * (e0 + k), n - 1)];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < CHUNK; ++k) {
+                const int e = e0 + k, j = t + 256 * e;
+                if (j < n) terms[heap_sum_pos(j)] = (q[e] - w[e]) * h[k];  // Q still holds the old value at column c
+                float su, sd;
+                st.get(e, q[e], g, su, sd);
+                const float f = two_dq * h[k];
+                const float nu = gu[e] + f * su, nd = gd[e] + f * sd;
+                gu[e] = j == c ? gu[e] : nu;
+                gd[e] = j == c ? gd[e] : nd;
+                // (slots in turn: left alone the scheduler runs all of them side by side, at three times the registers)
+                if (k % 2 == 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
         // np.sum(axis=-1) of the products, in NumPy's pairwise order: the sum feeds a gain that later moves compare
@@ -232,11 +286,12 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         if (t == ct) {
             const float d1u = cand_up(q_old, g) - q_old, d2u = cand_up(q_new, g) - q_new;
             const float d1d = cand_down(q_old, g) - q_old, d2d = cand_down(q_new, g) - q_new;
-            const float f = two_dq * h_cc;
+            const float f = two_dq * hd;  // H[c][c]: the diagonal holds the row's own element
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 if (e == ce) {
-                    if (KEEP) du[e] = d2u, dd[e] = d2d;
+                    float su2, sd2;
+                    st.set(e, q_new, g, su2, sd2);  // (= d2u, d2d)
                     float x = gu[e];
                     x = x + hd * (d1u * d1u - d2u * d2u);
                     x = x + (2.0f * s) * (d1u - d2u);
@@ -283,12 +338,15 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 // thread t, register set s holds chain t + 256 s; a wave's 8 leaves are a sub-tree of NumPy's recursion, the four waves'
 // sums meet in LDS as (T0 + T1) + (T2 + T3).  Two barriers per move (best move, sum) against the general kernel's five,
 // and no staging of the products: 684 -> 532 us for 4096 x 4096 with 10 moves, 242 -> 184 for 1024 x 4096.
-// KEEP: the candidate steps du / dd stay in registers (see k_local_search); for the one-wave-per-row form, which is bound by
-// the issue of its instructions (4096 x 1024, 10 moves: 150 -> 113 us).  The workgroup-per-row form is bound by the LATENCY of
-// a move (one trip to memory for the row of H, two barriers), which more resident rows hide and more registers do not
-// (1024 x 4096: 121 -> 132 us with them): it recomputes.
-template <int M8, int S, int WAVES, bool TABLE>
-__global__ __launch_bounds__(256) void k_local_search_wave(const float *__restrict__ W, float *__restrict__ Q,
+// CAND (see Steps): floats for the one-wave-per-row form, which is bound by the issue of its instructions and has registers to
+// spare (4096 x 1024, 10 moves: 150 -> 113 us); the workgroup-per-row form is bound by the LATENCY of a move (one trip to
+// memory for the row of H, two barriers, its own instructions one after the other), which resident rows hide and registers
+// cost (1024 x 4096 with floats: 121 -> 132 us, three rows a CU instead of four): packed levels there.
+#ifndef SLK_LS_WAVES_PER_SIMD
+#define SLK_LS_WAVES_PER_SIMD 4  // rows of 3072 / 4096 columns a CU keeps in flight (register cap 128)
+#endif
+template <int M8, int S, int WAVES, bool TABLE, int CAND>
+__global__ __launch_bounds__(256, (WAVES == 4 && S == 1 && CAND == 2 ? SLK_LS_WAVES_PER_SIMD : 1)) void k_local_search_wave(const float *__restrict__ W, float *__restrict__ Q,
                                                            PtrTable hs, int rpl, const float *__restrict__ G,
                                                            const float *__restrict__ hdiag, int R, int n, Grid g, int moves,
                                                            uint8_t *__restrict__ idx, int *__restrict__ trace,
@@ -297,6 +355,9 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
     constexpr int EPT = M8 * S;
     __shared__ Best red_up[4], red_dn[4];
     __shared__ float red_s[2][4];
+    // W of the row(s), slot-major (a thread reads only its own: consecutive lanes, consecutive banks): read once per move
+    // for the products, it need not hold EPT registers -- they decide how many rows a CU keeps in flight
+    __shared__ float wl[EPT][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row = WAVES == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
     if (row >= R) return;  // (WAVES == 1: whole waves, and no barrier anywhere below; WAVES == 4: the whole workgroup)
@@ -306,25 +367,20 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
     const int tr = WAVES == 1 ? lane : threadIdx.x;  // thread within the row
     const size_t base = (size_t)row * n;
     const float NEG = -__builtin_huge_valf();
-    int col[EPT];
-#pragma unroll
-    for (int s2 = 0; s2 < S; ++s2)
-#pragma unroll
-        for (int i = 0; i < M8; ++i) col[s2 * M8 + i] = ((tr >> 3) + 8 * WAVES * s2) * m + (tr & 7) + 8 * i;
-
-    // du / dd: the steps to the row's candidates, cand_up(q) - q and cand_down(q) - q (obq.py:257-258): pure functions of q, so
-    // they change with the moved column only.  Recomputed per element and move they were most of the kernel's instructions
-    // (a true division each: the search is bound by the ISSUE of its vector instructions, four waves a SIMD)
-    constexpr bool KEEP = WAVES == 1 && S == 1;
-    float w[EPT], q[EPT], gu[EPT], gd[EPT], du[KEEP ? EPT : 1], dd[KEEP ? EPT : 1];
+    // slot e = s2 * M8 + i of this thread: column col0 + 8 WAVES m s2 + 8 i, increasing with e (one register and constant
+    // offsets: as an array of EPT columns they cost EPT registers, and the row's loads a register each for their address)
+    const int col0 = (tr >> 3) * m + (tr & 7);
+    auto col = [&](int e) { return col0 + (e / M8) * (8 * WAVES * m) + 8 * (e % M8); };
+    float q[EPT], gu[EPT], gd[EPT];
+    Steps<EPT, CAND> st;
+    st.clear();
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int j = col[e];
-        w[e] = W[base + j];
+        const int j = col(e);
+        wl[e][threadIdx.x] = W[base + j];
         q[e] = Q[base + j];
-        const float su = cand_up(q[e], g) - q[e];
-        const float sd = cand_down(q[e], g) - q[e];
-        if (KEEP) du[e] = su, dd[e] = sd;
+        float su, sd;
+        st.set(e, q[e], g, su, sd);
         if (gains_mode == 2) {
             gu[e] = gains[2 * base + j];
             gd[e] = gains[2 * base + n + j];
@@ -343,10 +399,13 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
         Best bu = {NEG, 0x7fffffff, 0.0f}, bd = {NEG, 0x7fffffff, 0.0f};
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            // (a thread's columns increase with e: within a leaf by 8, and the second register set's leaves lie 8 WAVES further)
-            pick_first_max(bu, gu[e], col[e], q[e]);
-            pick_first_max(bd, gd[e], col[e], q[e]);
+            // (a thread's columns increase with e: within a leaf by 8, and the second register set's leaves lie 8 WAVES
+            // further.  The SLOT is what is tracked -- a constant per comparison; the columns would be EPT registers)
+            pick_first_max(bu, gu[e], e, q[e]);
+            pick_first_max(bd, gd[e], e, q[e]);
         }
+        bu.j = bu.j == 0x7fffffff ? bu.j : col0 + (S > 1 && bu.j >= M8 ? 8 * WAVES * m - 8 * M8 : 0) + 8 * bu.j;
+        bd.j = bd.j == 0x7fffffff ? bd.j : col0 + (S > 1 && bd.j >= M8 ? 8 * WAVES * m - 8 * M8 : 0) + 8 * bd.j;
         bu = wave_best(bu);
         bd = wave_best(bd);
         if (WAVES > 1) {
@@ -371,23 +430,29 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
         const float *hrow = H + (size_t)c * n;
         const float two_dq = 2.0f * (q_old - q_new);
         const float hd = hdiag[c];  // asked for with the row: after the sum it would be a second trip to memory per move
-        float h_cc = 0.0f, total = 0.0f;  // h_cc: H[c][c], met by the lane that owns column c
+        float total = 0.0f;
 #pragma unroll
         for (int s2 = 0; s2 < S; ++s2) {
+            // (every load of the set in flight before the first is waited for, then selects, not jumps: see k_local_search)
+            float h[M8];
+#pragma unroll
+            for (int i = 0; i < M8; ++i) h[i] = hrow[col(s2 * M8 + i)];
+            asm volatile("" ::: "memory");
             float acc = 0.0f;
 #pragma unroll
             for (int i = 0; i < M8; ++i) {
                 const int e = s2 * M8 + i;
-                const float h = hrow[col[e]];
-                const float p = (q[e] - w[e]) * h;  // Q still holds the old value at column c
+                const float p = (q[e] - wl[e][threadIdx.x]) * h[i];  // Q still holds the old value at column c
                 acc = i == 0 ? p : acc + p;
-                if (col[e] == c) {
-                    h_cc = h;
-                } else {
-                    const float f = two_dq * h;
-                    gu[e] = gu[e] + f * (KEEP ? du[e] : cand_up(q[e], g) - q[e]);
-                    gd[e] = gd[e] + f * (KEEP ? dd[e] : cand_down(q[e], g) - q[e]);
-                }
+                float su, sd;
+                st.get(e, q[e], g, su, sd);
+                const float f = two_dq * h[i];
+                const float nu = gu[e] + f * su, nd = gd[e] + f * sd;
+                const bool own = col(e) == c;  // the moved column keeps its gains here: rebuilt below
+                gu[e] = own ? gu[e] : nu;
+                gd[e] = own ? gd[e] : nd;
+                // (slots in turn: left alone the scheduler runs all of them side by side, at three times the registers)
+                if (i % 2 == 1) __builtin_amdgcn_sched_barrier(0);
             }
             // the leaf (8 accumulators = 8 lanes), then the 8 leaves of this register set
             acc = wave_sum_tree(acc);
@@ -402,10 +467,11 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
         const float ssum = 0.0f + total;  // (NumPy's reduction starts from 0 and adds the chunk's pairwise sum)
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            if (col[e] == c) {
-                const float hc = h_cc;
-                const float d1u = cand_up(q_old, g) - q_old, d2u = cand_up(q_new, g) - q_new;
-                const float d1d = cand_down(q_old, g) - q_old, d2d = cand_down(q_new, g) - q_new;
+            if (col(e) == c) {
+                const float hc = hd;  // H[c][c]: the diagonal holds the row's own element
+                const float d1u = cand_up(q_old, g) - q_old, d1d = cand_down(q_old, g) - q_old;
+                float d2u, d2d;
+                st.set(e, q_new, g, d2u, d2d);
                 const float f = two_dq * hc;
                 float x = gu[e];
                 x = x + hd * (d1u * d1u - d2u * d2u);
@@ -418,7 +484,6 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
                 y = y + f * d2d;
                 gd[e] = y;
                 q[e] = q_new;
-                if (KEEP) du[e] = d2u, dd[e] = d2d;
             }
         }
     }
@@ -428,7 +493,7 @@ __global__ __launch_bounds__(256) void k_local_search_wave(const float *__restri
 
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int j = col[e];
+        const int j = col(e);
         Q[base + j] = q[e];
         if (idx) idx[base + j] = (uint8_t)cb_index(q[e], g);
         if (gains_mode) {
@@ -473,16 +538,22 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
     const Grid g = make_grid(levels, lo, hi, table);
     const int ept = (n + 255) / 256;
     const size_t lds = (size_t)(n + 8 * (n / 128) + 8) * sizeof(float);  // heap_sum_floats(n)
-#define SLK_LS_T(E, T)                                                                                              \
+    // how the candidates are kept (Steps): floats on short rows, packed levels for a uniform grid of <= 256 levels
+    const bool small_grid = !g.table && levels <= 256;
+#define SLK_LS_T(E, T, C)                                                                                           \
     do {                                                                                                            \
-        SLK_LDS_OPT_IN((k_local_search<E, T>), lds);                                                                \
+        SLK_LDS_OPT_IN((k_local_search<E, T, C>), lds);                                                             \
         SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                       \
-                (k_local_search<E, T><<<R, 256, lds, s>>>(W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode, row_err_out))); \
+                (k_local_search<E, T, C><<<R, 256, lds, s>>>(W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode, row_err_out))); \
     } while (0)
 #define SLK_LS(E)                                                                                                   \
     do {                                                                                                            \
-        if (g.table) SLK_LS_T(E, true);                                                                             \
-        else SLK_LS_T(E, false);                                                                                    \
+        if (E <= 8) {                                                                                               \
+            if (g.table) SLK_LS_T(E, true, 1);                                                                      \
+            else SLK_LS_T(E, false, 1);                                                                             \
+        } else if (g.table) SLK_LS_T(E, true, 0);                                                                   \
+        else if (small_grid) SLK_LS_T(E, false, 2);                                                                 \
+        else SLK_LS_T(E, false, 0);                                                                                 \
     } while (0)
     // regular row lengths (8 or 16 leaves of m <= 128 elements, m % 8 == 0): one wave per row, no LDS, no barrier
     {
@@ -498,16 +569,18 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
         const int wave_opt = opt(OPT_NO_WAVE_SEARCH);  // 1: never, -1: whenever the row length allows (tests)
         regular = regular && m % 8 == 0 && m >= 8 && wave_opt <= 0;
         const int m8 = m / 8;
-#define SLK_LSW_T(M8, S, WAVES, T)                                                                                      \
+#define SLK_LSW_T(M8, S, WAVES, T, C)                                                                                   \
     SLK_RUN("local_search", 10.0 * n * R * moves, 4.0 * n * R * moves + 13.0 * R * n, s,                               \
-            (k_local_search_wave<M8, S, WAVES, T><<<WAVES == 1 ? (R + 3) / 4 : R, 256, 0, s>>>(                         \
+            (k_local_search_wave<M8, S, WAVES, T, C><<<WAVES == 1 ? (R + 3) / 4 : R, 256, 0, s>>>(                      \
                 W, Q, hs, rpl, G, hdiag, R, n, g, moves, idx, trace, gains, gains_mode, row_err_out)))
 #define SLK_LSW(M8, S, WAVES, LEAVES)                                                                                   \
     if (regular && m8 == M8 && leaves == LEAVES) {                                                                      \
-        if (g.table) SLK_LSW_T(M8, S, WAVES, true);                                                                     \
-        else SLK_LSW_T(M8, S, WAVES, false);                                                                            \
+        constexpr bool keep = WAVES == 1 && S == 1;                                                                     \
+        if (g.table) SLK_LSW_T(M8, S, WAVES, true, (keep ? 1 : 0));                                                     \
+        else SLK_LSW_T(M8, S, WAVES, false, (keep ? 1 : 2));                                                            \
         return SLK_OK;                                                                                                  \
     }
+        regular = regular && (g.table || small_grid);  // (a uniform grid of more than 256 levels: the general kernel)
         if (R >= 2048 || wave_opt < 0) {  // a wave per row: 8 or 16 leaves
             SLK_LSW(16, 1, 1, 8)   // n = 1024
             SLK_LSW(12, 1, 1, 8)   // n = 768

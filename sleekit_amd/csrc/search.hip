@@ -138,6 +138,16 @@ struct Steps {
             if (CAND == 1) du[E] = su, dd[E] = sd;
         }
     }
+    // slot E takes what `one` keeps for its slot 0
+    __device__ __forceinline__ void put(int E, const Steps<1, CAND> &one) {
+        if (CAND == 2) {
+            pu[E / 4] = byte_set(pu[E / 4], E % 4, one.pu[0] & 0xffu);
+            pd[E / 4] = byte_set(pd[E / 4], E % 4, one.pd[0] & 0xffu);
+        } else if (CAND == 1) {
+            du[E] = one.du[0];
+            dd[E] = one.dd[0];
+        }
+    }
     __device__ __forceinline__ void get(int E, float qv, const Grid g, float &su, float &sd) const {
         if (CAND == 2) {
             su = grid_val(byte_as_float(pu[E / 4], E % 4), g) - qv;
@@ -169,6 +179,9 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
     __shared__ Best red_up[4], red_dn[4];
     __shared__ HeapSum plan;
     extern __shared__ float terms[];  // heap_sum_floats(n): the products of the interaction sum, staged for NumPy's order
+    // ... followed by W of the row, slot-major (a thread reads only its own: consecutive lanes, consecutive banks): read once
+    // per move for the products, it need not hold EPT registers
+    float *wl = terms + ((heap_sum_floats(n) + 3) & ~3) + threadIdx.x;  // slot e at wl[256 e]
     const int row = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const size_t base = (size_t)row * n;
@@ -176,14 +189,14 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 
     heap_sum_plan(plan, n);
 
-    float w[EPT], q[EPT], gu[EPT], gd[EPT];
+    float q[EPT], gu[EPT], gd[EPT];
     Steps<EPT, CAND> st;
     st.clear();
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int j = t + 256 * e;
         if (j < n) {
-            w[e] = W[base + j];
+            wl[256 * e] = W[base + j];
             q[e] = Q[base + j];
             float su, sd;
             st.set(e, q[e], g, su, sd);
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
                 gd[e] = (-(sd * sd)) * hjj + (2.0f * gj) * sd;
             }
         } else {
-            w[e] = q[e] = 0.0f;
+            wl[256 * e] = q[e] = 0.0f;
             gu[e] = gd[e] = NEG;
             float su, sd;
             st.set(e, 0.0f, g, su, sd);
@@ -212,13 +225,20 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
     int mv = 0;
     for (; mv < moves; ++mv) {
         // ---- best up / best down of the row
+        // (the thread index through an opaque copy per move: everything formed from it below -- EPT load offsets, EPT
+        // positions of the staged products -- is loop-invariant, and hipcc keeps each in a register of its own across the
+        // moves otherwise: 2 EPT registers for values that cost one addition to form)
+        int tz = t;
+        asm volatile("" : "+v"(tz));
         Best bu = {NEG, 0x7fffffff, 0.0f}, bd = {NEG, 0x7fffffff, 0.0f};
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int j = t + 256 * e;
-            pick_first_max(bu, gu[e], j, q[e]);
-            pick_first_max(bd, gd[e], j, q[e]);
+            // (a thread's columns increase with the slot; the SLOT is tracked, a constant per comparison)
+            pick_first_max(bu, gu[e], e, q[e]);
+            pick_first_max(bd, gd[e], e, q[e]);
         }
+        bu.j = bu.j == 0x7fffffff ? bu.j : tz + 256 * bu.j;
+        bd.j = bd.j == 0x7fffffff ? bd.j : tz + 256 * bd.j;
         bu = wave_best(bu);
         bd = wave_best(bd);
         if (lane == 0) {  // (the previous move's readers of these slots passed the barriers of its sum)
@@ -233,9 +253,22 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         const bool go_up = (bu.v > bd.v) && (bu.v > 0.0f);
         const bool go_down = !go_up && (bd.v > 0.0f);
         if (!go_up && !go_down) break;  // uniform: nothing can change in later moves either
-        const int c = go_up ? bu.j : bd.j;
+        const int c = __builtin_amdgcn_readfirstlane(go_up ? bu.j : bd.j);
         const int ce = c >> 8, ct = c & 255;  // owner slot / thread of column c
         const float q_old = go_up ? bu.q : bd.q;
+        // ---- row c of H is asked for as soon as its number is known (with H[c][c], from the diagonal: after the sum it
+        // would be a second trip to memory per move); what only needs the decision is computed while the loads are out.
+        // All loads of (a chunk of) the row are issued before the first is waited for, and the slots then run the same
+        // instructions, selects instead of jumps: with `if (j == c) ... else ...` per slot hipcc put every load in a block
+        // of its own, right in front of its use -- sixteen trips to memory one after the other per move.  A slot beyond the
+        // row reads the row's last element; its gains stay -inf under any finite update.
+        const float *hrow = H + (size_t)c * n;
+        constexpr int CHUNK = EPT < 16 ? EPT : 16;
+        float h[CHUNK];
+#pragma unroll
+        for (int k = 0; k < CHUNK; ++k) h[k] = hrow[min(tz + 256 * k, n - 1)];
+        const float hd = hdiag[c];
+        asm volatile("" ::: "memory");
         const float q_new = go_up ? cand_up(q_old, g) : cand_down(q_old, g);
         // A "move" onto the value the weight already has (the up-candidate of the top level is the top level; a
         // rounding residue can leave such a candidate a positive gain): the reference carries it out, and every
@@ -249,32 +282,37 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
 
         // ---- stream row c of H: the products of the interaction sum with the OLD Q (obq.py:328), and part 2
         //      off the moved column
-        const float *hrow = H + (size_t)c * n;
         const float two_dq = 2.0f * (q_old - q_new);
-        const float hd = hdiag[c];  // asked for with the row: after the sum it would be a second trip to memory per move
+        // the moved column's candidates before and after the move (obq.py:322-334)
+        const float d1u = cand_up(q_old, g) - q_old, d1d = cand_down(q_old, g) - q_old;
+        Steps<1, CAND> moved;
+        moved.clear();
+        float d2u, d2d;
+        moved.set(0, q_new, g, d2u, d2d);
+        const float sq_u = d1u * d1u - d2u * d2u, sq_d = d1d * d1d - d2d * d2d;
+        const float df_u = d1u - d2u, df_d = d1d - d2d;
 
-        // All loads of (a chunk of) the row are issued before the first is waited for, and the slots then run the same
-        // instructions, selects instead of jumps: with `if (j == c) ... else ...` per slot hipcc put every load in a block
-        // of its own, right in front of its use -- sixteen trips to memory one after the other per move.  A slot beyond the
-        // row reads the row's last element; its gains stay -inf under any finite update.  The moved column's own slot keeps
-        // its gains here (rebuilt below).
-        constexpr int CHUNK = EPT < 16 ? EPT : 16;
+        // ---- the products of the interaction sum with the OLD Q (obq.py:328), and part 2 off the moved column (whose own
+        //      slot keeps its gains here: rebuilt below)
 #pragma unroll
         for (int e0 = 0; e0 < EPT; e0 += CHUNK) {
-            float h[CHUNK];
+            if (e0 > 0) {
 #pragma unroll
-            for (int k = 0; k < CHUNK; ++k) h[k] = hrow[min(t + 256 * (e0 + k), n - 1)];
-            asm volatile("" ::: "memory");
+                for (int k = 0; k < CHUNK; ++k) h[k] = hrow[min(tz + 256 * (e0 + k), n - 1)];
+                asm volatile("" ::: "memory");
+            }
 #pragma unroll
             for (int k = 0; k < CHUNK; ++k) {
-                const int e = e0 + k, j = t + 256 * e;
-                if (j < n) terms[heap_sum_pos(j)] = (q[e] - w[e]) * h[k];  // Q still holds the old value at column c
-                float su, sd;
-                st.get(e, q[e], g, su, sd);
-                const float f = two_dq * h[k];
-                const float nu = gu[e] + f * su, nd = gd[e] + f * sd;
-                gu[e] = j == c ? gu[e] : nu;
-                gd[e] = j == c ? gd[e] : nd;
+                const int e = e0 + k, j = tz + 256 * e;
+                if (e < EPT) {
+                    if (j < n) terms[heap_sum_pos(j)] = (q[e] - wl[256 * e]) * h[k];  // Q still holds the old value at column c
+                    float su, sd;
+                    st.get(e, q[e], g, su, sd);
+                    const float f = two_dq * h[k];
+                    const float nu = gu[e] + f * su, nd = gd[e] + f * sd;
+                    gu[e] = j == c ? gu[e] : nu;
+                    gd[e] = j == c ? gd[e] : nd;
+                }
                 // (slots in turn: left alone the scheduler runs all of them side by side, at three times the registers)
                 if (k % 2 == 1) __builtin_amdgcn_sched_barrier(0);
             }
@@ -282,27 +320,25 @@ __global__ __launch_bounds__(256) void k_local_search(const float *__restrict__ 
         // np.sum(axis=-1) of the products, in NumPy's pairwise order: the sum feeds a gain that later moves compare
         const float s = heap_sum(plan, terms, n);
 
-        // ---- the moved column: diagonal term, interaction part 1, then part 2 (obq.py:322-334)
+        // ---- the moved column: diagonal term, interaction part 1, then part 2 with H[c][c] (the diagonal holds the row's
+        //      own element), each rounded in turn (obq.py:322-334)
         if (t == ct) {
-            const float d1u = cand_up(q_old, g) - q_old, d2u = cand_up(q_new, g) - q_new;
-            const float d1d = cand_down(q_old, g) - q_old, d2d = cand_down(q_new, g) - q_new;
-            const float f = two_dq * hd;  // H[c][c]: the diagonal holds the row's own element
+            const float f_cc = two_dq * hd, s2x = 2.0f * s;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 if (e == ce) {
-                    float su2, sd2;
-                    st.set(e, q_new, g, su2, sd2);  // (= d2u, d2d)
                     float x = gu[e];
-                    x = x + hd * (d1u * d1u - d2u * d2u);
-                    x = x + (2.0f * s) * (d1u - d2u);
-                    x = x + f * d2u;
+                    x = x + hd * sq_u;
+                    x = x + s2x * df_u;
+                    x = x + f_cc * d2u;
                     gu[e] = x;
                     float y = gd[e];
-                    y = y + hd * (d1d * d1d - d2d * d2d);
-                    y = y + (2.0f * s) * (d1d - d2d);
-                    y = y + f * d2d;
+                    y = y + hd * sq_d;
+                    y = y + s2x * df_d;
+                    y = y + f_cc * d2d;
                     gd[e] = y;
                     q[e] = q_new;
+                    st.put(e, moved);
                 }
             }
         }
@@ -422,22 +458,37 @@ __global__ __launch_bounds__(256, (WAVES == 4 && S == 1 && CAND == 2 ? SLK_LS_WA
         if (!go_up && !go_down) break;
         const int c = go_up ? bu.j : bd.j;
         const float q_old = go_up ? bu.q : bd.q;
+        // the row of H is asked for as soon as its number is known (with H[c][c], from the diagonal: after the sum it would
+        // be a second trip to memory per move); what only needs the decision is computed while the loads are out
+        const float *hrow = H + (size_t)c * n;
+        float h[M8];
+#pragma unroll
+        for (int i = 0; i < M8; ++i) h[i] = hrow[col(i)];
+        const float hd = hdiag[c];
+        asm volatile("" ::: "memory");
         const float q_new = go_up ? cand_up(q_old, g) : cand_down(q_old, g);
         if (q_new == q_old) break;  // a "move" onto the same value: see k_local_search
         if (trace && tr == 0) trace[(size_t)row * moves + mv] = 2 * c + (go_up ? 1 : 0);
         e_run = e_run - (go_up ? bu.v : bd.v);
-
-        const float *hrow = H + (size_t)c * n;
         const float two_dq = 2.0f * (q_old - q_new);
-        const float hd = hdiag[c];  // asked for with the row: after the sum it would be a second trip to memory per move
+        // the moved column's candidates before and after the move (obq.py:322-334)
+        const float d1u = cand_up(q_old, g) - q_old, d1d = cand_down(q_old, g) - q_old;
+        Steps<1, CAND> moved;
+        moved.clear();
+        float d2u, d2d;
+        moved.set(0, q_new, g, d2u, d2d);
+        const float sq_u = d1u * d1u - d2u * d2u, sq_d = d1d * d1d - d2d * d2d;
+        const float df_u = d1u - d2u, df_d = d1d - d2d;
+
         float total = 0.0f;
 #pragma unroll
         for (int s2 = 0; s2 < S; ++s2) {
-            // (every load of the set in flight before the first is waited for, then selects, not jumps: see k_local_search)
-            float h[M8];
+            // (every load of a set in flight before the first is waited for, then selects, not jumps: see k_local_search)
+            if (s2 > 0) {
 #pragma unroll
-            for (int i = 0; i < M8; ++i) h[i] = hrow[col(s2 * M8 + i)];
-            asm volatile("" ::: "memory");
+                for (int i = 0; i < M8; ++i) h[i] = hrow[col(s2 * M8 + i)];
+                asm volatile("" ::: "memory");
+            }
             float acc = 0.0f;
 #pragma unroll
             for (int i = 0; i < M8; ++i) {
@@ -465,25 +516,31 @@ __global__ __launch_bounds__(256, (WAVES == 4 && S == 1 && CAND == 2 ? SLK_LS_WA
             if (S > 1) total = total + ((red_s[1][0] + red_s[1][1]) + (red_s[1][2] + red_s[1][3]));
         }
         const float ssum = 0.0f + total;  // (NumPy's reduction starts from 0 and adds the chunk's pairwise sum)
+        // the moved column: diagonal term, interaction part 1, then part 2 with H[c][c] (the diagonal holds the row's own
+        // element), each rounded in turn (obq.py:322-334)
+        const float f_cc = two_dq * hd, s2x = 2.0f * ssum;
+        // its owner: leaf c / m, accumulator chain (c % m) & 7 -> thread; slot (leaf / (8 WAVES)) M8 + (c % m) / 8.  c is
+        // wave-uniform: one lane goes in, and the slot is picked by scalar compares
+        const int leaf = c / m, within = c - leaf * m;
+        const int ce = (leaf / (8 * WAVES)) * M8 + (within >> 3);
+        const int ct = ((leaf % (8 * WAVES)) << 3) | (within & 7);
+        if (tr == ct) {
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            if (col(e) == c) {
-                const float hc = hd;  // H[c][c]: the diagonal holds the row's own element
-                const float d1u = cand_up(q_old, g) - q_old, d1d = cand_down(q_old, g) - q_old;
-                float d2u, d2d;
-                st.set(e, q_new, g, d2u, d2d);
-                const float f = two_dq * hc;
-                float x = gu[e];
-                x = x + hd * (d1u * d1u - d2u * d2u);
-                x = x + (2.0f * ssum) * (d1u - d2u);
-                x = x + f * d2u;
-                gu[e] = x;
-                float y = gd[e];
-                y = y + hd * (d1d * d1d - d2d * d2d);
-                y = y + (2.0f * ssum) * (d1d - d2d);
-                y = y + f * d2d;
-                gd[e] = y;
-                q[e] = q_new;
+            for (int e = 0; e < EPT; ++e) {
+                if (e == ce) {
+                    float x = gu[e];
+                    x = x + hd * sq_u;
+                    x = x + s2x * df_u;
+                    x = x + f_cc * d2u;
+                    gu[e] = x;
+                    float y = gd[e];
+                    y = y + hd * sq_d;
+                    y = y + s2x * df_d;
+                    y = y + f_cc * d2d;
+                    gd[e] = y;
+                    q[e] = q_new;
+                    st.put(e, moved);
+                }
             }
         }
     }
@@ -537,7 +594,8 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
     SLK_RUN("extract_diag", 0, 8.0 * n * batch, s, k_extract_diag<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(hs, n, hdiag));
     const Grid g = make_grid(levels, lo, hi, table);
     const int ept = (n + 255) / 256;
-    const size_t lds = (size_t)(n + 8 * (n / 128) + 8) * sizeof(float);  // heap_sum_floats(n)
+    // heap_sum_floats(n) for the staged products, then W of the row (256 floats per slot)
+    const size_t lds = (size_t)(((n + 8 * (n / 128) + 8 + 3) & ~3) + 256 * std::max(4, (ept <= 8 ? (ept <= 4 ? 4 : 8) : ept <= 16 ? 16 : ept <= 32 ? 32 : ept <= 48 ? 48 : 64))) * sizeof(float);
     // how the candidates are kept (Steps): floats on short rows, packed levels for a uniform grid of <= 256 levels
     const bool small_grid = !g.table && levels <= 256;
 #define SLK_LS_T(E, T, C)                                                                                           \

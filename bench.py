@@ -829,10 +829,18 @@ def main():
                 _lib.lib.slk_profile_reset()
             k = rep_.get("local_search")
             if k:
-                search[f"moves_{mv}"] = {"us": round(1e3 * k["total_ms"], 1), "us_per_move": round(1e3 * k["total_ms"] / mv, 2),
-                                         "achieved_gb_s": round(k["bytes"] / (k["total_ms"] * 1e-3) / 1e9, 1),
-                                         "frac": round(k["bytes"] / (k["total_ms"] * 1e-3) / PEAK["hbm"][0], 4)}
-        search["algorithmic_bytes"] = "moves x R x 4 n (one streamed row of H per row and move) + 13 R n (state in and out), SURVEY.md 8d"
+                # the moves the rows actually took (a row stops when nothing is left to gain): an untimed run with the record
+                Qs = base.Q.clone()
+                rec = engine.local_search(Ws, Qs, lay["H"], engine.require_uniform(head.cb), mv, want_trace=True)
+                taken = int((rec >= 0).sum().item())
+                R_, n_ = shapes[0]
+                moved_bytes = 4.0 * n_ * taken + 13.0 * R_ * n_
+                search[f"moves_{mv}"] = {"us": round(1e3 * k["total_ms"], 1), "moves_taken_per_row": round(taken / R_, 2),
+                                         "us_per_move_taken": round(1e3 * k["total_ms"] / max(taken / R_, 1e-9), 2),
+                                         "achieved_gb_s": round(moved_bytes / (k["total_ms"] * 1e-3) / 1e9, 1),
+                                         "frac": round(moved_bytes / (k["total_ms"] * 1e-3) / PEAK["hbm"][0], 4)}
+                del rec
+        search["algorithmic_bytes"] = "moves TAKEN x 4 n (one streamed row of H per row and move taken) + 13 R n (state in and out), SURVEY.md 8d"
         del Ws, base
 
     # ---- a1, Hessian accumulation, timed as its own stage: 2048-token batches into an n x n Hessian

@@ -622,9 +622,10 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
             m /= 2;
             leaves *= 2;
         }
-        // (measured, 10 moves: 3072 x 1024 135 -> 95 us, 4096 x 1024 170 -> 154, but 1024 x 1024 68 -> 80: with few rows either
-        // kernel is the latency of one move after the other, and the wave kernel's shuffles are LDS-crossbar permutes)
-        const int wave_opt = opt(OPT_NO_WAVE_SEARCH);  // 1: never, -1: whenever the row length allows (tests)
+        // (round 3 kept few rows on the general kernel -- 1024 x 1024: 68 against 80 us, the wave kernel's shuffles were LDS
+        // permutes then; since round 4 the wave kernel wins at every height: 1024 x 1024 x 10 moves 48 -> 29 us, 128 x 1024
+        // 39 -> 27)
+        const int wave_opt = opt(OPT_NO_WAVE_SEARCH);  // 1: never (tests: the general kernel on regular rows)
         regular = regular && m % 8 == 0 && m >= 8 && wave_opt <= 0;
         const int m8 = m / 8;
 #define SLK_LSW_T(M8, S, WAVES, T, C)                                                                                   \
@@ -639,12 +640,11 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
         return SLK_OK;                                                                                                  \
     }
         regular = regular && (g.table || small_grid);  // (a uniform grid of more than 256 levels: the general kernel)
-        if (R >= 2048 || wave_opt < 0) {  // a wave per row: 8 or 16 leaves
-            SLK_LSW(16, 1, 1, 8)   // n = 1024
-            SLK_LSW(12, 1, 1, 8)   // n = 768
-            SLK_LSW(16, 2, 1, 16)  // n = 2048
-            SLK_LSW(12, 2, 1, 16)  // n = 1536
-        }
+        // a wave per row: 8 or 16 leaves
+        SLK_LSW(16, 1, 1, 8)   // n = 1024
+        SLK_LSW(12, 1, 1, 8)   // n = 768
+        SLK_LSW(16, 2, 1, 16)  // n = 2048
+        SLK_LSW(12, 2, 1, 16)  // n = 1536
         // a workgroup per row, a chain per thread: 32 or 64 leaves
         SLK_LSW(16, 1, 4, 32)  // n = 4096
         SLK_LSW(12, 1, 4, 32)  // n = 3072

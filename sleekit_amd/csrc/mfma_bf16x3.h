@@ -145,6 +145,14 @@ struct TileBf16DmaSmem {
 };
 __device__ __forceinline__ int swizzled_chunk(int row, int c) { return c ^ ((row >> 2) & 3); }
 
+// SLK_BF16_COPY_AFTER_HALF = 1 (round 4): every operand read of a round is issued up front (a scheduling barrier keeps hipcc from
+// sinking the second k-half's reads to their MFMAs), the MFMAs of the first k-half run while the second half's reads land,
+// and only then comes the barrier behind which the next round's copy is issued.  Same MFMAs in the same order.  Layer error
+// of a 4096 x 4096 layer, alternating on one box: 449 / 474 / 457 us -> 443 / 409 / 423.  (0: wait for all reads, barrier, copy,
+// then the round's MFMAs.)
+#ifndef SLK_BF16_COPY_AFTER_HALF
+#define SLK_BF16_COPY_AFTER_HALF 1
+#endif
 // a_slabs / b_slabs: this tile's slab of K-step 0 in plane 0 (consecutive steps 4096 elements apart, planes *_plane apart).
 __device__ __forceinline__ void tile128_mac_dma(Acc128 &acc, TileBf16DmaSmem &sm, int k_begin, int k_end,
                                                 const unsigned short *__restrict__ a_slabs, size_t a_plane,
@@ -188,14 +196,15 @@ __device__ __forceinline__ void tile128_mac_dma(Acc128 &acc, TileBf16DmaSmem &sm
                     b[s][i][p] = *reinterpret_cast<const bf16x8_t *>(sm.b[p] + (wc * 64 + i * 32) * 64 + (s ? r_off1 : r_off0));
                 }
         ga += 4096, gb += 4096;
-        if (k0 + KB16 < k_end) {
-            // (the reads above must have completed in EVERY wave before the copy overwrites the buffer)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __syncthreads();
-            copy_round(ga, gb);
-        }
+        if (SLK_BF16_COPY_AFTER_HALF) __builtin_amdgcn_sched_barrier(0);  // every read of the round is issued before its first MFMA
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+            if (s == SLK_BF16_COPY_AFTER_HALF && k0 + KB16 < k_end) {
+                // (the reads above must have completed in EVERY wave before the copy overwrites the buffer)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                copy_round(ga, gb);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -209,6 +218,7 @@ __device__ __forceinline__ void tile128_mac_dma(Acc128 &acc, TileBf16DmaSmem &sm
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][0], b[s][j][0], c, 0, 0, 0);
                     acc.c[i][j] = c;
                 }
+        }
     }
 }
 
@@ -306,6 +316,122 @@ __device__ __forceinline__ void tile256_mac(Acc128 &acc, TileBf16TallSmem &sm, i
             mac(1);
         }
     }
+}
+
+// ---- 256 x 256 tiles over K in steps of 16 (round 4, the verdict's form).  At 128 x 128 the kernel runs at the rate a CU
+// pulls operands out of L2 (48 KB per 6.3 Mflop); a 256 x 256 tile moves the same 48 KB per 12.6 Mflop.  512 threads, wave w =
+// rows 64 (w >> 1), columns 128 (w & 1): 2 x 4 blocks of 32 x 32, 128 accumulator registers.  One workgroup per CU, so nothing
+// else hides a round's waits: the operands come by global_load_lds into a RING OF THREE images (144 KB), the copy of round
+// r + 2 issued at the top of round r, ONE barrier per round.  hipcc cannot tell an LDS read from the landing of such a copy
+// and would wait for every copy in flight before each read; the reads are therefore inline assembly with their own
+// s_waitcnt, the barrier is the bare instruction.  Planes in the K16 layout of k_split3 (lay16): slab (256-row block, 16-k
+// step) = [k half][256 rows][8 k], 8 KB contiguous per plane -- copied verbatim, read as lane l: row l & 31, half l >> 5:
+// 512 contiguous bytes per half-wave, conflict-free.  Same six products per element and 16-k step, steps in order: every
+// accumulator is the 128 x 128 kernel's bit for bit.
+struct Acc256 {
+    float16_t c[2][4];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[i][j][r] = 0.0f;
+    }
+};
+constexpr int BIG = 256;        // tile edge
+constexpr int BIG_RING = 3;     // images in flight
+constexpr int BIG_IMAGE = 2 * 3 * 8192;  // bytes per round: A and B, three planes of [2][256][8] bfloat16 each
+struct TileBf16BigSmem {
+    unsigned char ring[BIG_RING][BIG_IMAGE];  // [image][operand 0 = A, 1 = B][plane][8192]
+};
+__device__ __forceinline__ bf16x8_t lds_read16_asm(unsigned addr) {
+    bf16x8_t v;
+#ifndef SLK_BIG_NO_READS
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+#else
+    asm volatile("; no read %0 %1" : "=v"(v) : "v"(addr));  // (timing only)
+#endif
+    return v;
+}
+// a_slabs / b_slabs: plane 0 of this tile's slab of K-step 0 (consecutive 16-k steps 4096 elements apart, planes *_plane apart);
+// rounds = (k_end - k_begin) / 16.  Ends with every copy landed and every read done (a barrier): the LDS is free afterwards.
+__device__ __forceinline__ void tile256sq_mac(Acc256 &acc, TileBf16BigSmem &sm, int k_begin, int k_end,
+                                              const unsigned short *__restrict__ a_slabs, size_t a_plane,
+                                              const unsigned short *__restrict__ b_slabs, size_t b_plane) {
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int rounds = (k_end - k_begin) >> 4;
+    if (rounds <= 0) return;
+    // this wave's eighth of a slab plane: 1 KB = one instruction of 64 lanes x 16 bytes
+    const unsigned short *ga = a_slabs + (size_t)(k_begin >> 4) * 4096 + wave * 512 + lane * 8;
+    const unsigned short *gb = b_slabs + (size_t)(k_begin >> 4) * 4096 + wave * 512 + lane * 8;
+    auto copy_round = [&](int r) {  // round r of this call into image r % 3
+        unsigned char *img = sm.ring[r % BIG_RING] + wave * 1024;
+        const unsigned short *pa = ga + (size_t)r * 4096, *pb = gb + (size_t)r * 4096;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            __builtin_amdgcn_global_load_lds(pa + p * a_plane, img + p * 8192, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(pb + p * b_plane, img + 3 * 8192 + p * 8192, 16, 0, 0);
+        }
+    };
+    // LDS byte addresses of this lane's operands in image 0: A block i at + 512 i, B block j at + 512 j, plane p at + 8192 p
+    const unsigned lds0 = (unsigned)(uintptr_t)&sm.ring[0][0];
+    const unsigned a_rd = lds0 + (lane >> 5) * 4096 + (wr * 64 + (lane & 31)) * 16;
+    const unsigned b_rd = lds0 + 3 * 8192 + (lane >> 5) * 4096 + (wc * 128 + (lane & 31)) * 16;
+    __builtin_amdgcn_s_barrier();  // whatever used this LDS before is done (the caller's earlier reads were waited for)
+    copy_round(0);
+    if (rounds > 1) copy_round(1);
+    for (int r = 0; r < rounds; ++r) {
+        // this wave's copies of round r have landed (those of round r + 1, issued a round ago, may still be out)
+#if defined(SLK_BIG_NO_WAIT)
+        if (r + 1 == rounds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (timing only: rounds read whatever has landed)
+#elif !defined(SLK_BIG_NO_COPY)
+        if (r + 1 < rounds) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifndef SLK_BIG_NO_BARRIER
+        __builtin_amdgcn_s_barrier();  // every wave's have; and every wave is through with the reads of round r - 1
+#endif
+#ifndef SLK_BIG_NO_COPY
+        if (r + 2 < rounds) copy_round(r + 2);  // into the image round r - 1 was read from
+#endif
+        const unsigned img = (unsigned)(r % BIG_RING) * BIG_IMAGE;
+        bf16x8_t a[2][3], b[4][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[0][p] = lds_read16_asm(a_rd + img + p * 8192);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[1][p] = lds_read16_asm(a_rd + img + p * 8192 + 512);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[j][p] = lds_read16_asm(b_rd + img + p * 8192 + 512 * j);
+        // four accumulators' chains side by side (columns j0, j0 + 1 of both row blocks), the six products of each in the
+        // 128 x 128 kernel's order
+        auto mac4 = [&](int j0) {
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc.c[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t6]], b[j0 + jj][PB[t6]], acc.c[i][j0 + jj], 0, 0, 0);
+        };
+        // 18 reads are out, in the order a0 a1 b0 b1 b2 b3 (three planes each); LDS returns in order.
+        // (scheduling barriers: nothing ties a wait to the MFMAs before it, and hipcc otherwise hoists all the waits in front
+        // of the first MFMA -- the reads would no longer run under the MFMAs)
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]),
+                     "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2])::"memory");
+        mac4(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[2][2]), "+v"(b[3][0]), "+v"(b[3][1]), "+v"(b[3][2])::"memory");
+        mac4(2);
+    }
+    __builtin_amdgcn_s_barrier();  // every wave is through with the last image
 }
 
 }  // namespace slk

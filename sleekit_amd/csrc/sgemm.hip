@@ -160,6 +160,8 @@ __global__ __launch_bounds__(256) void k_error_tiles(const float *__restrict__ W
 // would otherwise be split once per tile that uses it (32 times at n = 4096).
 // blockIdx.y: the layer of a stack (its own x, flag and planes: out + blockIdx.y * 3 * plane); one launch for a round's
 // Hessians -- eight 4 MB matrices split one by one are eight launches of 17 us each, bound by nothing but their number.
+// swz == 2: the K16 layout of the 256 x 256 tiles (mfma_bf16x3.h, tile256sq_mac): slab (256-row block rb, 16-k step ks) =
+// [k half][256 rows][8 k], no swizzle.
 __global__ __launch_bounds__(256) void k_split3(PtrTable xs, const float *__restrict__ y, int rows, int n,
                                                 unsigned short *__restrict__ out, size_t plane,
                                                 const int *__restrict__ sym_flag, int swz, int band_only, int average) {
@@ -174,18 +176,30 @@ __global__ __launch_bounds__(256) void k_split3(PtrTable xs, const float *__rest
     const size_t quads = plane / 4;  // groups of four consecutive k
     for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (size_t)gridDim.x * blockDim.x) {
         const size_t e = qd * 4;                      // position in the plane
-        const int k4 = (int)(e & 31), r = (int)((e >> 5) & 127);
         const size_t slab = e >> 12;                  // rb * ksteps + ks
-        const int ks = (int)(slab % ksteps), rb = (int)(slab / ksteps);
-        // (a symmetric H whose error alone is wanted: tile column rb of the GEMM reads the k steps up to its diagonal
-        // band only, k < 128 (rb + 1) -- the other half of the plane is never looked at)
-        if (band_only && ks >= 4 * (rb + 1)) continue;
-        const int row = min(rb * 128 + r, rows - 1);
-        const size_t src = (size_t)row * n + ks * 32 + k4;
+        int k4, r, row, kcol;
+        if (swz == 2) {
+            const int w = (int)(e & 4095), ksteps16 = n / 16;
+            const int ks = (int)(slab % ksteps16), rb = (int)(slab / ksteps16);
+            r = (w >> 3) & 255;
+            k4 = w & 7;
+            if (band_only && ks >= 16 * (rb + 1)) continue;  // (tile column rb reads k < 256 (rb + 1))
+            row = min(rb * 256 + r, rows - 1);
+            kcol = ks * 16 + (w >> 11) * 8 + k4;
+        } else {
+            k4 = (int)(e & 31), r = (int)((e >> 5) & 127);
+            const int ks = (int)(slab % ksteps), rb = (int)(slab / ksteps);
+            // (a symmetric H whose error alone is wanted: tile column rb of the GEMM reads the k steps up to its diagonal
+            // band only, k < 128 (rb + 1) -- the other half of the plane is never looked at)
+            if (band_only && ks >= 4 * (rb + 1)) continue;
+            row = min(rb * 128 + r, rows - 1);
+            kcol = ks * 32 + k4;
+        }
+        const size_t src = (size_t)row * n + kcol;
         float4_t v = *reinterpret_cast<const float4_t *>(x + src);
         if (avg) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = 0.5f * (v[c] + x[(size_t)(ks * 32 + k4 + c) * n + row]);
+            for (int c = 0; c < 4; ++c) v[c] = 0.5f * (v[c] + x[(size_t)(kcol + c) * n + row]);
         }
         if (y) {
             const float4_t u = *reinterpret_cast<const float4_t *>(y + src);
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(256) void k_split3(PtrTable xs, const float *__rest
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             // (swz: the 16-byte chunk moves inside its row, see tile128_mac_dma)
-            const size_t eo = swz ? (e & ~(size_t)31) + (size_t)(swizzled_chunk(r, k4 >> 3) * 8 + (k4 & 7)) : e;
+            const size_t eo = swz == 1 ? (e & ~(size_t)31) + (size_t)(swizzled_chunk(r, k4 >> 3) * 8 + (k4 & 7)) : e;
             unsigned *o = reinterpret_cast<unsigned *>(out + (size_t)p * plane + eo);
             o[0] = w[p][0];
             o[1] = w[p][1];
@@ -456,6 +470,121 @@ __global__ __launch_bounds__(512) void k_error_tiles_bf16_tall(const float *__re
     if (threadIdx.x < TALL) partial[(size_t)(r0 + threadIdx.x) * p_stride + tile_x] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
 }
 
+// The same product on 256 x 256 tiles (mfma_bf16x3.h: tile256sq_mac; "tall_error" = 2): half the bytes out of L2 per flop.
+// One workgroup (512 threads, 144 KB of LDS) per CU at a time, so the tiles themselves must balance:
+//   * the product wanted (G, the local search's): every tile runs all of K -- equal work; XCD x (workgroups x, x + 8, ...)
+//     takes patches of 4 x 8 tiles, 12 slab sets per round for its 32 CUs;
+//   * the error of a symmetric H alone: tile column x needs the k blocks 0 ... x (the part under its diagonal band twice,
+//     the band once), a triangle of depths 1 ... n / 256.  It is cut into ITEMS of two 256-k blocks (one for the band of an
+//     even column), each with its own slot of partial row sums; XCD x takes the row tiles x, x + 8, ... and walks the items,
+//     the two-block ones first.
+// Every accumulator is the 128 x 128 kernel's bit for bit (same products, same order over k); the partial sums of a row are
+// added in another order (256 columns and two k blocks per slot), so the row errors agree to rounding, not bit for bit.
+__global__ __launch_bounds__(512) void k_error_tiles_bf16_big(const float *__restrict__ W, const float *__restrict__ Q,
+                                                                 const unsigned short *__restrict__ Dp, const unsigned short *__restrict__ Hp,
+                                                                 int R, int n, float *__restrict__ partial, const int *__restrict__ sym_flag,
+                                                                 int p_stride, int rpl, float *__restrict__ G, int asym_mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TileBf16BigSmem &sm = *reinterpret_cast<TileBf16BigSmem *>(smem_raw);
+    __shared__ float rowpart[2][BIG];
+    const int n_rt = R / BIG, n_ct = n / BIG;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int tile_x, tile_y, blk_lo, blk_hi, p_slot;
+    if (G != nullptr) {
+        const int pr_n = (n_rt + 3) / 4, pc_n = (n_ct + 7) / 8;
+        const int patch = xcd + 8 * (slot >> 5), in_patch = slot & 31;
+        if (patch >= pr_n * pc_n) return;
+        tile_y = (patch / pc_n) * 4 + (in_patch & 3);
+        tile_x = (patch % pc_n) * 8 + (in_patch >> 2);
+        if (tile_y >= n_rt || tile_x >= n_ct) return;
+        blk_lo = 0, blk_hi = n_ct, p_slot = tile_x;
+    } else {
+        const int rows_here = (n_rt - xcd + 7) / 8;  // row tiles xcd, xcd + 8, ...
+        if (rows_here <= 0) return;
+        const int q = slot / rows_here;
+        tile_y = xcd + 8 * (slot - q * rows_here);
+        // item q: the two-block chunks of every column first (column x has (x + 1) / 2 of them), then the single blocks of
+        // the even columns.  Slots: column x starts at sum_{x' < x} ceil((x' + 1) / 2).
+        int count2 = 0;
+        for (int x = 0; x < n_ct; ++x) count2 += (x + 1) / 2;
+        if (q >= count2 + (n_ct + 1) / 2) return;
+        int chunk;
+        if (q < count2) {
+            int x = 0, left = q;
+            while (left >= (x + 1) / 2) left -= (x + 1) / 2, ++x;
+            tile_x = x, chunk = left;
+            blk_lo = 2 * chunk, blk_hi = 2 * chunk + 2;
+        } else {
+            tile_x = 2 * (q - count2), chunk = tile_x / 2;
+            blk_lo = tile_x, blk_hi = tile_x + 1;
+        }
+        p_slot = chunk;
+        for (int x = 0; x < tile_x; ++x) p_slot += (x + 2) / 2;
+    }
+    const int r0 = tile_y * BIG, j0 = tile_x * BIG;
+    const int layer = r0 / rpl;
+    const bool full_k = G != nullptr;
+    if (sym_flag[layer] <= 0 && !asym_mode) return;  // (not symmetric and no averaged planes: the float32 kernel's rows)
+    Hp += (size_t)layer * 3 * n * n;
+    Acc256 acc;
+    acc.zero();
+    const int ksteps = n / 16;
+    const size_t d_plane = (size_t)R * n, h_plane = (size_t)n * n;
+    const unsigned short *a_slabs = Dp + (size_t)tile_y * ksteps * 4096, *b_slabs = Hp + (size_t)tile_x * ksteps * 4096;
+    if (full_k) {
+        tile256sq_mac(acc, sm, 0, n, a_slabs, d_plane, b_slabs, h_plane);
+    } else {
+        const int k_lo = blk_lo * BIG, k_below = min(blk_hi * BIG, j0);  // [k_lo, k_below) lies under the band: twice
+        if (k_below > k_lo) {
+            tile256sq_mac(acc, sm, k_lo, k_below, a_slabs, d_plane, b_slabs, h_plane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc.c[i][j][r] = acc.c[i][j][r] * 2.0f;
+        }
+        if (blk_hi == tile_x + 1) tile256sq_mac(acc, sm, j0, j0 + BIG, a_slabs, d_plane, b_slabs, h_plane);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // epilogue as in k_error_tiles_bf16: a half sub-tile's differences fetched together (rows beyond R do not exist here: whole
+    // tiles), the sixteen row sums down the lane tree side by side
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float dd[16][4], sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t o = (size_t)(r0 + row) * n + j0 + wc * 128 + j * 32 + (lane & 31);
+                dd[r][j] = W[o] - Q[o];
+                if (G) G[o] = acc.c[i][j][r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sacc = sacc + acc.c[i][j][r] * dd[r][j];
+            sv[r] = sacc;
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = sv[r] + __shfl_xor(sv[r], m, 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if ((lane & 31) == 0) rowpart[wc][row] = sv[r];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < BIG) partial[(size_t)(r0 + threadIdx.x) * p_stride + p_slot] = rowpart[0][threadIdx.x] + rowpart[1][threadIdx.x];
+}
+
 // flag[0] = 1 iff H is bit-wise symmetric (flag must be preset to 1).  One workgroup per pair of mirrored
 // 64 x 64 tiles (a triangular list of pairs): tile (bi, bj) goes to LDS through coalesced 16-byte loads, tile
 // (bj, bi) is read the same way and compared with the transpose out of LDS -- every element is read once.
@@ -711,6 +840,15 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
             if (n_rt * slots >= 512 || force) break;
         }
     }
+    // whole layers on 256 x 256 tiles ("tall_error" = 2, k_error_tiles_bf16_big): slots of its own (one per tile column with
+    // G, one per item of the triangle without); the float32 kernel's n_tiles slots stay addressable
+    const bool big = cb == 0 && R % BIG == 0 && rpl % BIG == 0 && n % BIG == 0 && R / BIG >= 8 && opt(OPT_TALL_ERROR) == 2 &&
+                     !opt(OPT_NO_BF16_DMA) && !opt(OPT_NO_SYM_ERROR) && !opt(OPT_NO_BF16_ERROR) && !(G == nullptr && opt(OPT_NO_SYM_AVERAGE));
+    int big_items = 0;
+    if (big) {
+        for (int x = 0; x < n / BIG; ++x) big_items += (x + 2) / 2;
+        n_slots = std::max(n_tiles, G ? n / BIG : big_items);
+    }
     float *partial = ws.take<float>((size_t)R * n_slots);
     int *sym = ws.take<int>(64);
     if (!partial || !sym) {
@@ -718,7 +856,7 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
         return SLK_E_WS;
     }
     hipStream_t s = as_stream(stream);
-    if (cb > 0) zero_async(partial, (size_t)R * n_slots * sizeof(float), s);  // the float32 kernel fills n_tiles slots only
+    if (cb > 0 || big) zero_async(partial, (size_t)R * n_slots * sizeof(float), s);  // the float32 kernel fills n_tiles slots only
     dim3 grid(8 * ((n_tiles * n_rt + 7) / 8));  // a multiple of the 8 XCDs: see the tile order in the kernel
     bool aligned = ((uintptr_t)W | (uintptr_t)Q) % 16 == 0;
     HPtrs hp;
@@ -747,7 +885,8 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     // a Hessian that is NOT symmetric stays on the bfloat16 kernel too (planes of H^T, every k) unless K is cut into chunks
     // ... or, when only the error is wanted (no G), is AVERAGED with its transpose on the way into the planes (asym_mode 2):
     // d H d^T = d ((H + H^T) / 2) d^T, so every Hessian takes the symmetric half-product route
-    const int asym_mode = !bf16_ok ? 0 : (G == nullptr && !opt(OPT_NO_SYM_AVERAGE)) ? 2 : (cb == 0 && !opt(OPT_NO_BF16_ASYM)) ? 1 : 0;
+    // (256 x 256 tiles: no transposed planes in their layout -- with G a Hessian that is not symmetric goes to the float32 kernel)
+    const int asym_mode = !bf16_ok ? 0 : (G == nullptr && !opt(OPT_NO_SYM_AVERAGE)) ? 2 : (cb == 0 && !opt(OPT_NO_BF16_ASYM) && !big) ? 1 : 0;
     if (batch > 1 && !few_rows && !(Dp && Hp)) {
         set_error("workspace too small for the operand planes of %d layers (slk_workspace_bytes_batch)", batch);
         return SLK_E_WS;
@@ -761,7 +900,7 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
     if (bf16_ok) {
         SLK_LDS_OPT_IN(k_error_tiles_bf16<false>, sizeof(TileBf16Smem));
         SLK_LDS_OPT_IN(k_error_tiles_bf16<true>, sizeof(TileBf16DmaSmem));
-        const int dma = !opt(OPT_NO_BF16_DMA);  // operands to LDS by global_load_lds (swizzled planes)
+        const int dma = big ? 2 : !opt(OPT_NO_BF16_DMA);  // operands to LDS by global_load_lds (1: swizzled planes, 2: the K16 layout)
         SLK_RUN("error_split", 0, 14.0 * R * n, s,
                 k_split3<<<2048, 256, 0, s>>>(one_ptr(W), Q, R, n, Dp, d_plane, batch == 1 && !asym_mode ? sym : nullptr, dma, 0, 0));
         {
@@ -781,7 +920,15 @@ static int row_errors_impl(const float *W, const float *Q, const float *const *H
         // epilogues were batched (round 4); since then the square tiles, two workgroups to a CU so that one's epilogue runs
         // under the other's MFMAs, are ahead (451 against 489 us on one box).
         const bool tall = dma && cb == 0 && R % TALL == 0 && rpl % TALL == 0 && R / TALL >= 8 && opt(OPT_TALL_ERROR) == 1;
-        if (tall) {
+        if (big) {
+            SLK_LDS_OPT_IN(k_error_tiles_bf16_big, sizeof(TileBf16BigSmem));
+            const int n_rt_b = R / BIG, n_ct_b = n / BIG;
+            const int wgs_big = G ? 8 * 32 * ((((n_rt_b + 3) / 4) * ((n_ct_b + 7) / 8) + 7) / 8)
+                                  : 8 * ((n_rt_b + 7) / 8) * big_items;
+            SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, 2 * wgs_big, s,
+                      k_error_tiles_bf16_big<<<wgs_big, 512, sizeof(TileBf16BigSmem), s>>>(W, Q, Dp, Hp, R, n, partial, sym, n_slots, rpl, G,
+                                                                                             asym_mode));
+        } else if (tall) {
             SLK_LDS_OPT_IN(k_error_tiles_bf16_tall, sizeof(TileBf16TallSmem));
             const int wgs_tall = 8 * ((R / TALL + 7) / 8) * ((n_tiles + 7) / 8 * 8);
             SLK_RUN_W("error_gemm_bf16", 6.0 * R * n * (n + (double)T32), 6.0 * R * n + 3.0 * n * n * batch, 2 * (R / TALL) * n_tiles, s,

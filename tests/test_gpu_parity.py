@@ -624,6 +624,50 @@ def test_layer_error_on_tall_tiles_is_the_square_tile_kernel(amd, slkopt):
     np.testing.assert_allclose(tall[1].cpu().numpy(), one.cpu().numpy(), rtol=2e-6)
 
 
+def test_layer_error_on_256_tiles(amd, slkopt):
+    """Whole layers CAN take 256 x 256 tiles (option tall_error = 2; k_error_tiles_bf16_big: K in steps of 16 through a ring of
+    three LDS images filled by global_load_lds, planes in the K16 layout).  Same six products per element and 16-k step in
+    the same order: the product G = (W - Q) H is the square-tile kernel's BIT FOR BIT; a row's partial sums are added in
+    another order (256 columns and two k blocks per slot), so the row errors agree to rounding.  Symmetric H, an H that is
+    not symmetric (averaged planes without G, the float32 kernel with it), and a stack of layers."""
+    rng = np.random.default_rng(29)
+    for R, n in ((2304, 1024), (2048, 2304)):  # nine row tiles / nine column tiles: partial patches and XCDs without a row tile
+        W = torch.from_numpy(rng.standard_normal((R, n)).astype(np.float32)).cuda()
+        Q = W + 0.2 * torch.from_numpy(rng.standard_normal((R, n)).astype(np.float32)).cuda()
+        X = rng.standard_normal((2 * n, n)).astype(np.float32)
+        H = (X.T @ X / (2 * n)).astype(np.float32)
+        H = ((H + H.T) * np.float32(0.5)).astype(np.float32)
+        Ha = (H + np.float32(0.05) * np.triu(rng.standard_normal((n, n)).astype(np.float32), 1)).astype(np.float32)
+        Hs, Has = torch.from_numpy(H).cuda(), torch.from_numpy(Ha).cuda()
+
+        def both(fn):
+            square = fn()
+            slkopt.setenv("SLK_TALL_ERROR", "2")
+            big = fn()
+            slkopt.delenv("SLK_TALL_ERROR")
+            return big, square
+
+        for Hx in (Hs, Has):
+            big, square = both(lambda: amd.engine.row_errors(W, Q, Hx))
+            np.testing.assert_allclose(big.cpu().numpy(), square.cpu().numpy(), rtol=2e-6)
+            (e1, G1), (e2, G2) = both(lambda: amd.engine.row_errors(W, Q, Hx, want_G=True))
+            if Hx is Hs:
+                assert torch.equal(G1, G2)
+            else:  # (not symmetric, G wanted: the float32 kernel here, transposed planes on the square tiles)
+                np.testing.assert_allclose(G1.cpu().numpy(), G2.cpu().numpy(), rtol=0, atol=2e-5)
+            np.testing.assert_allclose(e1.cpu().numpy(), e2.cpu().numpy(), rtol=2e-6)
+        D = (W - Q).double().cpu().numpy()
+        want = ((D @ H.astype(np.float64)) * D).sum(axis=1)
+        slkopt.setenv("SLK_TALL_ERROR", "2")
+        np.testing.assert_allclose(amd.engine.row_errors(W, Q, Hs).cpu().numpy(), want, rtol=1e-5)
+        slkopt.delenv("SLK_TALL_ERROR")
+        if R % 768 == 0:
+            H2 = torch.from_numpy(((H * np.float32(1.25)) + np.float32(0.01) * np.eye(n, dtype=np.float32))).cuda()
+            Wb, Qb = W.view(3, 768, n).contiguous(), Q.view(3, 768, n).contiguous()
+            big, square = both(lambda: amd.engine.row_errors_batch(Wb, Qb, [Hs, H2, Has]))
+            np.testing.assert_allclose(big.cpu().numpy(), square.cpu().numpy(), rtol=2e-6)
+
+
 def test_layer_error_bf16_path(amd, slkopt):
     """The layer error of a symmetric Hessian runs on the bfloat16 MFMA with three pieces per operand
     (six products): every row within 1e-5 of the float64 value, like the float32 kernel it replaces --

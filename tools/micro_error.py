@@ -12,12 +12,13 @@ Q = W + 0.1 * torch.randn(R, n, device="cuda", generator=g)
 X = torch.randn(n, n, device="cuda", generator=g)
 H = (X @ X.t()) / n
 H = (H + H.t()) * 0.5
+WANT_G = bool(int(os.environ.get("WANT_G", "0")))  # the full product G = (W - Q) H (the local search's), not the error alone
 for rep in range(2):
-    engine.row_errors(W, Q, H)
+    engine.row_errors(W, Q, H, want_G=WANT_G)
 torch.cuda.synchronize()
 _lib.lib.slk_profile_reset(); _lib.lib.slk_profile_enable(1)
 for rep in range(5):
-    engine.row_errors(W, Q, H)
+    engine.row_errors(W, Q, H, want_G=WANT_G)
 torch.cuda.synchronize(); _lib.lib.slk_profile_enable(0)
 for k in _lib.profile_report():
     print(f"   {k['kernel']:<18s} {k['launches']//5:4d}/call  avg {1e3*k['total_ms']/k['launches']:8.2f} us  {k['flops']/max(k['total_ms'],1e-9)/1e9:8.2f} TFLOP/s (algorithmic)")

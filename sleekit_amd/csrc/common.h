@@ -85,7 +85,7 @@ enum Opt {
     OPT_LOOKAHEAD,             // factorisation: the bulk of an outer syrk on a helper stream, beside the next block's panels
     OPT_WINDOW_ROWS,           // window kernel: rows per workgroup forced to 16 or 32 (0: 32, or 16 where the caller asks for latency)
     OPT_PANEL_SPLIT,           // factorisation: 0 / 3: an outer block's panels as a chain of workgroups in one launch; 1 / 2: the panel kernel, two launches / one per panel
-    OPT_TALL_ERROR,            // layer error: 256 x 128 tiles for whole layers (from 2048 rows up; default: 128 x 128 everywhere)
+    OPT_TALL_ERROR,            // layer error of whole layers (from 2048 rows up): 1 = 256 x 128 tiles, 2 = 256 x 256 tiles over K16 (default: 128 x 128 everywhere)
     OPT_ROWS_BELOW_WIDE,       // factorisation: the rows below a diagonal block 64 rows per workgroup (1) or 16 (2) whatever the batch (0: 64 from 1024 strips per launch up)
     OPT_COUNT
 };

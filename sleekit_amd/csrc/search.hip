@@ -606,12 +606,14 @@ static int local_search_impl(const float *W, float *Q, const float *const *Hs, i
     } while (0)
 #define SLK_LS(E)                                                                                                   \
     do {                                                                                                            \
-        if (E <= 8) {                                                                                               \
+        if constexpr (E <= 8) { /* short rows: the steps as floats */                                               \
             if (g.table) SLK_LS_T(E, true, 1);                                                                      \
             else SLK_LS_T(E, false, 1);                                                                             \
-        } else if (g.table) SLK_LS_T(E, true, 0);                                                                   \
-        else if (small_grid) SLK_LS_T(E, false, 2);                                                                 \
-        else SLK_LS_T(E, false, 0);                                                                                 \
+        } else {                                                                                                    \
+            if (g.table) SLK_LS_T(E, true, 0);                                                                      \
+            else if (small_grid) SLK_LS_T(E, false, 2);                                                             \
+            else SLK_LS_T(E, false, 0);                                                                             \
+        }                                                                                                           \
     } while (0)
     // regular row lengths (8 or 16 leaves of m <= 128 elements, m % 8 == 0): one wave per row, no LDS, no barrier
     {

@@ -319,7 +319,9 @@ def quantize_layer(
         else:
             miss = column_miss(Ws, cb_abi, mode == _lib.ORDER_SQERR) if mode >= _lib.ORDER_ERR else None
         factor = factorize(H, n, damp, mode, miss, lookahead=lookahead)
-        dev.note_info(factor[2], "compute_hessian_chol")
+        check_factor = True
+    else:
+        check_factor = False
     res.order, res.U, res.info = factor
 
     # without local search the loop's last kernel de-scales on the way out (one pass over Q less)
@@ -331,4 +333,10 @@ def quantize_layer(
         res.ls_trace = local_search(Ws, res.Q, H, cb_abi, nb_ls_moves, res.idx, want_trace=want_ls_trace, row_err=res.ls_error)
     if scale is not None and unscale and not fused:
         res.Q = rows_divide(res.Q, scale, invert=True)
+    # The factorisation's status word is read back only now, with the loop (and the search) already enqueued behind it: read
+    # right after the factorisation, the round trip to the host kept the loop's first launch waiting 35-45 us per layer.  A
+    # matrix that is not positive definite still raises here (numpy.linalg.LinAlgError, as np.linalg.cholesky does in
+    # sleekit/obq.py:49-50); the loop then ran on a void factor, memory-safe, its results never returned.
+    if check_factor:
+        dev.note_info(res.info, "compute_hessian_chol")
     return res

@@ -846,6 +846,33 @@ def test_local_search_wave_kernel_is_the_workgroup_kernel(amd, n):
         assert len(bad) <= 1  # (a near-tie of the initial product may fall the other way: proven elsewhere, ls_evidence.py)
 
 
+@pytest.mark.parametrize("kind", ["nf4", "uniform300"])
+def test_local_search_kernels_on_other_codebooks(amd, kind):
+    """The search kernels' other instantiations: a general codebook (binary searches; candidates kept as floats or
+    recomputed) and a uniform grid of more than 256 levels (no packed levels: the general kernel, recomputing) -- the
+    chain-per-lane kernels against the general one bit for bit on regular rows, and both against the oracle."""
+    cb = amd.codebook.Codebook.nf4() if kind == "nf4" else amd.codebook.UniformCodebook(300, -1, 1)
+    g = grid.TableGrid.nf4() if kind == "nf4" else grid.UniformGrid(300, -1, 1)
+    abi = cb._abi()
+    for n, R in ((1024, 22), (4096, 6), (1100, 10)):
+        L = synth.make_layer_device(R, n, 4400 + n, torch.device("cuda"))
+        Ws = amd.engine.rows_divide(L["W"], L["scale"])
+        Q0 = torch.from_numpy(g(Ws.cpu().numpy())).cuda()
+        out = []
+        for general in (-1, 1):
+            with amd.lib.option("no_wave_search", general):
+                Q = Q0.clone()
+                gains = torch.empty((R, 2, n), dtype=torch.float32, device="cuda")
+                trace = amd.engine.local_search(Ws, Q, L["H"], abi, 9, None, want_trace=True, gains=gains, gains_mode=1)
+                out.append((Q, trace, gains))
+        for a, b in zip(out[0], out[1]):
+            assert torch.equal(a, b), (kind, n)
+        assert int((out[0][1] >= 0).sum()) > R
+        want = obq_ref.local_search(Ws.cpu().numpy(), Q0.cpu().numpy(), L["H"].cpu().numpy(), g, 9)
+        bad = np.flatnonzero((out[0][0].cpu().numpy() != want).any(axis=1))
+        assert len(bad) <= 1, (kind, n, bad)  # (a near-tie of the initial product may fall the other way: ls_evidence.py)
+
+
 @pytest.mark.parametrize("n", [172, 768, 1024, 4096])
 def test_local_search_carries_the_row_errors(amd, n):
     """slk_local_search's `row_err`: every row's error (W - Q) H (W - Q)^T after the moves, carried through the search the way

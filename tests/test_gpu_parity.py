@@ -354,6 +354,28 @@ def test_factor_of_plain_matrix_and_not_pd(amd):
         obq_ref.inverse_factor_upper(M)
 
 
+@pytest.mark.parametrize("n", [96, 1024])
+def test_layer_with_an_indefinite_hessian_raises_like_the_reference(amd, n):
+    """sleekit/obq.py:49-50: np.linalg.cholesky raises LinAlgError for a Hessian that is not positive definite.  The single-layer
+    API reads the factorisation's status word back AFTER the loop (and the search) are enqueued -- the round trip used to hold
+    up the loop's first launch -- so the loop runs on a void factor before the exception comes: still the reference's
+    exception, nothing returned, and the next layer is unaffected."""
+    L = layer(40, n, 2070 + n)
+    cb = amd.codebook.UniformCodebook(8, -1, 1)
+    good = amd.scaling.quantize_with_scaling(L["W"], L["scale"], cb, L["H"], act_order="diag", damp=0.01, nb_ls_moves=3)
+    H = L["H"].copy()
+    k = n // 2
+    H[k, :] = 0
+    H[:, k] = 0
+    H[k, k] = -10.0 * np.abs(L["H"]).max()  # stays negative under 1 % damping
+    with pytest.raises(np.linalg.LinAlgError):
+        amd.scaling.quantize_with_scaling(L["W"], L["scale"], cb, H, act_order="diag", damp=0.01, nb_ls_moves=3)
+    with pytest.raises(np.linalg.LinAlgError):
+        amd.obq.quantize_opt(L["W"], H, cb)
+    again = amd.scaling.quantize_with_scaling(L["W"], L["scale"], cb, L["H"], act_order="diag", damp=0.01, nb_ls_moves=3)
+    assert np.array_equal(good, again)
+
+
 def test_orders_err_sqerr(amd):
     L = layer(64, 96, 2001)
     g = grid.UniformGrid(8, -1, 1)

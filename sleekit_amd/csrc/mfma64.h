@@ -174,6 +174,13 @@ __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_beg
     const double *a_src1 = a_src + a_off1;
     const double *b_src1 = b_src + b_off1;
     for (int k0 = k_begin; k0 < k_end; k0 += KSTEP) {
+#ifdef SLK_T64_NO_STAGE  // (timing only: one image, no loads, no barriers after the first step)
+        if (k0 == k_begin) {
+            __syncthreads();
+            stash();
+            __syncthreads();
+        }
+#else
         __syncthreads();  // previous step's LDS reads are done
         stash();
         __syncthreads();
@@ -181,21 +188,29 @@ __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_beg
             la(k0 + KSTEP, ra);
             lb(k0 + KSTEP, rb);
         }
+#endif
         // operands of group kk + 4 are read from LDS before the MFMAs of group kk are issued
+#ifdef SLK_T64_NO_READS  // (timing only: the MFMAs alone, on whatever the registers hold)
+        double a0n = 1.0, a1n = 2.0, b0n = 3.0, b1n = 4.0;
+        asm volatile("" : "+v"(a0n), "+v"(a1n), "+v"(b0n), "+v"(b1n));
+#else
         double a0n = a_src[0], a1n = a_src1[0];
         double b0n = b_src[0], b1n = b_src1[0];
+#endif
         // (fence: otherwise these four are fused with the reads of group 4 just below into ds_read2_b64 /
         // ds_read2st64_b64 -- a quarter of all operand reads, and the remaining bank conflicts)
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int kk = 0; kk < KSTEP; kk += 4) {
             const double a0 = a0n, a1 = a1n, b0 = b0n, b1 = b1n;
+#ifndef SLK_T64_NO_READS
             if (kk + 4 < KSTEP) {
                 a0n = a_src[kk + 4];
                 a1n = a_src1[kk + 4];
                 b0n = B_C_FAST ? b_src[(kk + 4) * PITCH_KC] : b_src[kk + 4];
                 b1n = B_C_FAST ? b_src1[(kk + 4) * PITCH_KC] : b_src1[kk + 4];
             }
+#endif
             asm volatile("" : "+v"(acc.c[0][0]), "+v"(acc.c[0][1])::"memory");  // keep the reads above the MFMAs
             acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.c[0][0], 0, 0, 0);
             acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.c[0][1], 0, 0, 0);

@@ -650,7 +650,11 @@ namespace slk {
 __global__ __launch_bounds__(256) void k_gptq_trailing(float *__restrict__ Qp, const float *__restrict__ Eg,
                                                        const double *__restrict__ U, int R, int n, int ka, int kb,
                                                        int ja, int jb, int vec_ok, int rpl) {
+#ifdef SLK_TRAILING_F64_IMAGE
     __shared__ __attribute__((aligned(16))) Tile64Smem sm;
+#else
+    __shared__ __attribute__((aligned(16))) Tile64SmemAf sm;  // E stays float32 in LDS (mfma64.h)
+#endif
     const int r0 = blockIdx.y * TILE, j0 = ja + blockIdx.x * TILE;
     U += (size_t)(r0 / rpl) * n * n;  // batch of layers stacked by rows (rpl a multiple of the tile)
     const int t = threadIdx.x;

@@ -27,6 +27,8 @@
 //   D: register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15]
 #pragma once
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace slk {
@@ -43,6 +45,16 @@ constexpr int PITCH_KC = 80;   // [k][col] image
 struct Tile64Smem {
     double a[TILE * PITCH_RK];
     double b[KSTEP * PITCH_KC];  // >= TILE * PITCH_RK
+};
+
+// The same with a float32 A operand kept as float32 in LDS (k_gptq_trailing: A = E): half the A image (9 KB instead of 17: five
+// workgroups to a CU instead of four, a quarter less LDS write traffic per K-step), widened AFTER the LDS read.  Row pitch 36
+// floats: a thread's 8 consecutive k go down as two ds_write_b128, and the operand read (lane l: row l & 15, k l >> 4) walks
+// banks 36 row + k -- 36 r mod 64 are the sixteen multiples of 4, so the 64 lanes cover the 64 banks.
+constexpr int PITCH_AF = 36;
+struct Tile64SmemAf {
+    float a[TILE * PITCH_AF];
+    double b[KSTEP * PITCH_KC];
 };
 
 struct Acc64 {
@@ -138,21 +150,30 @@ __device__ __forceinline__ void load8f_as_d_guarded(const float *p, int last, bo
 // TA: type of the A fragment held in registers between its global load and the LDS write (double, or
 // float for a float32 operand: the widening then happens at the LDS write, a whole MFMA phase after the
 // load was issued -- converted at once it would make the wave wait for the load before its MFMAs).
-template <bool B_C_FAST, class TA = double, class LA, class LB>
-__device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_begin, int k_end, LA la, LB lb) {
+template <bool B_C_FAST, class TA = double, class SM, class LA, class LB>
+__device__ __forceinline__ void tile64_mac(Acc64 &acc, SM &sm, int k_begin, int k_end, LA la, LB lb) {
+    constexpr bool AF = std::is_same<SM, Tile64SmemAf>::value;  // A stays float32 in LDS
+    static_assert(!AF || (std::is_same<TA, float>::value && B_C_FAST), "the float32 A image is for float32 A and column-contiguous B");
+    using TL = typename std::conditional<AF, float, double>::type;  // element type of the A image
+    constexpr int PITCH_A = AF ? PITCH_AF : PITCH_RK;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     TA ra[8];
     double rb[8];
-    double *a_dst = sm.a + (t >> 2) * PITCH_RK + (t & 3) * 8;
+    TL *a_dst = sm.a + (t >> 2) * PITCH_A + (t & 3) * 8;
     double *b_dst = B_C_FAST ? sm.b + (t >> 3) * PITCH_KC + (t & 7) * 2 : sm.b + (t >> 2) * PITCH_RK + (t & 3) * 8;
     constexpr int B_PIECE = B_C_FAST ? 16 : 2;  // distance between a thread's pieces in the image
 
     auto stash = [&]() {
+        if constexpr (AF) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                *reinterpret_cast<float4v_t *>(a_dst + 4 * h) = (float4v_t){(float)ra[4 * h], (float)ra[4 * h + 1], (float)ra[4 * h + 2], (float)ra[4 * h + 3]};
+        }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            *reinterpret_cast<double2_t *>(a_dst + 2 * h) = (double2_t){(double)ra[2 * h], (double)ra[2 * h + 1]};
+            if constexpr (!AF) *reinterpret_cast<double2_t *>(a_dst + 2 * h) = (double2_t){(double)ra[2 * h], (double)ra[2 * h + 1]};
             *reinterpret_cast<double2_t *>(b_dst + B_PIECE * h) = (double2_t){rb[2 * h], rb[2 * h + 1]};
         }
     };
@@ -160,7 +181,7 @@ __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_beg
     if (k_begin >= k_end) return;
     la(k_begin, ra);
     lb(k_begin, rb);
-    const double *a_src = sm.a + (wr * 32 + (lane & 15)) * PITCH_RK + (lane >> 4);
+    const TL *a_src = sm.a + (wr * 32 + (lane & 15)) * PITCH_A + (lane >> 4);
     const double *b_src = B_C_FAST ? sm.b + (lane >> 4) * PITCH_KC + wc * 32 + (lane & 15)
                                    : sm.b + (wc * 32 + (lane & 15)) * PITCH_RK + (lane >> 4);
     // The second operand of each pair gets a base of its own that the compiler cannot relate to the
@@ -169,9 +190,9 @@ __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_beg
     // out for ds_read_b64 (32-lane halves, 64 banks).  Measured: 46 % of the LDS cycles were conflicts.
     // (the distance goes through an opaque register; laundering the pointer itself would lose the
     // LDS address space and turn the reads into flat loads)
-    int a_off1 = 16 * PITCH_RK, b_off1 = B_C_FAST ? 16 : 16 * PITCH_RK;
+    int a_off1 = 16 * PITCH_A, b_off1 = B_C_FAST ? 16 : 16 * PITCH_RK;
     asm volatile("" : "+v"(a_off1), "+v"(b_off1));
-    const double *a_src1 = a_src + a_off1;
+    const TL *a_src1 = a_src + a_off1;
     const double *b_src1 = b_src + b_off1;
     for (int k0 = k_begin; k0 < k_end; k0 += KSTEP) {
 #ifdef SLK_T64_NO_STAGE  // (timing only: one image, no loads, no barriers after the first step)
@@ -191,10 +212,11 @@ __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_beg
 #endif
         // operands of group kk + 4 are read from LDS before the MFMAs of group kk are issued
 #ifdef SLK_T64_NO_READS  // (timing only: the MFMAs alone, on whatever the registers hold)
-        double a0n = 1.0, a1n = 2.0, b0n = 3.0, b1n = 4.0;
+        TL a0n = 1.0, a1n = 2.0;
+        double b0n = 3.0, b1n = 4.0;
         asm volatile("" : "+v"(a0n), "+v"(a1n), "+v"(b0n), "+v"(b1n));
 #else
-        double a0n = a_src[0], a1n = a_src1[0];
+        TL a0n = a_src[0], a1n = a_src1[0];
         double b0n = b_src[0], b1n = b_src1[0];
 #endif
         // (fence: otherwise these four are fused with the reads of group 4 just below into ds_read2_b64 /
@@ -202,7 +224,7 @@ __device__ __forceinline__ void tile64_mac(Acc64 &acc, Tile64Smem &sm, int k_beg
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int kk = 0; kk < KSTEP; kk += 4) {
-            const double a0 = a0n, a1 = a1n, b0 = b0n, b1 = b1n;
+            const double a0 = (double)a0n, a1 = (double)a1n, b0 = b0n, b1 = b1n;  // (AF: widened here, after the LDS read)
 #ifndef SLK_T64_NO_READS
             if (kk + 4 < KSTEP) {
                 a0n = a_src[kk + 4];
